@@ -1,0 +1,105 @@
+"""Oracle: host tail of the detector (numpy).  TEST INFRASTRUCTURE.
+
+Follows src/lib/utils/post_process.py:105-122 (polydet_post_process),
+src/lib/utils/image.py:19-66 (transform_preds / get_affine_transform /
+affine_transform) and src/lib/detectors/polydet.py:45-76.
+`cv2.getAffineTransform` (image.py:56,58) is the exact affine through three
+point pairs; restated as a 6x6 linear solve in float64.
+"""
+import numpy as np
+
+
+def _third_point(a, b):
+    d = a - b
+    return b + np.array([-d[1], d[0]], dtype=np.float32)
+
+
+def affine_from_3pts(src, dst):
+    A = np.zeros((6, 6), dtype=np.float64)
+    rhs = np.zeros(6, dtype=np.float64)
+    for k in range(3):
+        A[2 * k, 0:3] = (src[k, 0], src[k, 1], 1.0)
+        A[2 * k + 1, 3:6] = (src[k, 0], src[k, 1], 1.0)
+        rhs[2 * k], rhs[2 * k + 1] = dst[k, 0], dst[k, 1]
+    return np.linalg.solve(A, rhs).reshape(2, 3)
+
+
+def get_affine_transform(center, scale, rot, output_size, inv=0):
+    """image.py:27-60 with rot in degrees, shift = 0."""
+    if not isinstance(scale, (np.ndarray, list)):
+        scale = np.array([scale, scale], dtype=np.float32)
+    src_w = scale[0]
+    dst_w, dst_h = output_size[0], output_size[1]
+    rot_rad = np.pi * rot / 180
+    sn, cs = np.sin(rot_rad), np.cos(rot_rad)
+    sp = [0, src_w * -0.5]
+    src_dir = np.array([sp[0] * cs - sp[1] * sn, sp[0] * sn + sp[1] * cs])
+    dst_dir = np.array([0, dst_w * -0.5], np.float32)
+    src = np.zeros((3, 2), dtype=np.float32)
+    dst = np.zeros((3, 2), dtype=np.float32)
+    src[0, :] = center
+    src[1, :] = center + src_dir
+    dst[0, :] = [dst_w * 0.5, dst_h * 0.5]
+    dst[1, :] = np.array([dst_w * 0.5, dst_h * 0.5], np.float32) + dst_dir
+    src[2, :] = _third_point(src[0, :], src[1, :])
+    dst[2, :] = _third_point(dst[0, :], dst[1, :])
+    if inv:
+        return affine_from_3pts(np.float32(dst), np.float32(src))
+    return affine_from_3pts(np.float32(src), np.float32(dst))
+
+
+def transform_preds(coords, center, scale, output_size):
+    """image.py:19-24: per-row fp32 [x,y,1] times the float64 2x3 matrix."""
+    t = get_affine_transform(center, scale, 0, output_size, inv=1)
+    pts = np.concatenate([coords[:, 0:2].astype(np.float32),
+                          np.ones((coords.shape[0], 1), np.float32)], axis=1)
+    out = np.zeros(coords.shape)
+    out[:, 0:2] = pts @ t.T
+    return out
+
+
+def polydet_post_process(dets, c, s, h, w, num_classes):
+    """post_process.py:105-122."""
+    ret = []
+    for i in range(dets.shape[0]):
+        top = {}
+        dets[i, :, :2] = transform_preds(dets[i, :, 0:2], c[i], s[i], (w, h))
+        dets[i, :, 2:4] = transform_preds(dets[i, :, 2:4], c[i], s[i], (w, h))
+        for j in range(6, dets.shape[-1] - 1, 2):
+            dets[i, :, j:j + 2] = transform_preds(dets[i, :, j:j + 2], c[i], s[i], (w, h))
+        classes = dets[i, :, 5]
+        for j in range(num_classes):
+            inds = classes == j
+            top[j + 1] = np.concatenate([dets[i, inds, :4].astype(np.float32),
+                                         dets[i, inds, 4:5].astype(np.float32),
+                                         dets[i, inds, 6:].astype(np.float32)], axis=1).tolist()
+        ret.append(top)
+    return ret
+
+
+def detector_post_process(dets, meta, scale, num_classes):
+    """detectors/polydet.py:45-60."""
+    dets = dets.reshape(1, -1, dets.shape[2])
+    out = polydet_post_process(dets.copy(), [meta["c"]], [meta["s"]],
+                               meta["out_height"], meta["out_width"], num_classes)
+    width = dets.shape[2] - 1
+    for j in range(1, num_classes + 1):
+        a = np.array(out[0][j], dtype=np.float32).reshape(-1, width)
+        a[:, :4] /= scale
+        a[:, 5:-1] /= scale
+        out[0][j] = a
+    return out[0]
+
+
+def merge_outputs(detections, num_classes, max_per_image):
+    """detectors/polydet.py:62-76 without soft-nms (single scale, --nms off)."""
+    results = {}
+    for j in range(1, num_classes + 1):
+        results[j] = np.concatenate([d[j] for d in detections], axis=0).astype(np.float32)
+    scores = np.hstack([results[j][:, 4] for j in range(1, num_classes + 1)])
+    if len(scores) > max_per_image:
+        kth = len(scores) - max_per_image
+        thresh = np.partition(scores, kth)[kth]
+        for j in range(1, num_classes + 1):
+            results[j] = results[j][results[j][:, 4] >= thresh]
+    return results

@@ -1,0 +1,251 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REFERENCE's own Python on CPU.
+
+Runs only in the build container (needs /root/reference); the fixtures it
+writes are data (expected outputs), inputs are regenerated from
+centerpoly_amd.synth by stream name, so no reference text is stored.
+
+Recipe = SURVEY.md Appendix D: put src/lib on sys.path, stub the two modules
+that are imported-but-unused on the arithmetic path (cv2, seaborn).  For the
+DLASeg golden the reference's plugin slot `models.networks.DCNv2.dcn_v2.DCN`
+is filled with the oracle's DCN (the reference has none), so that golden pins
+everything AROUND DCN (base, IDA wiring, up-convs, heads), not DCN itself.
+
+Usage:  python tests/golden/gen_golden.py            (writes next to this file)
+"""
+import json
+import math
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+REF = "/root/reference/src/lib"
+
+from centerpoly_amd import synth  # noqa: E402
+from oracle import dcn as odcn    # noqa: E402
+from oracle import post as opost  # noqa: E402
+
+
+def _import_reference():
+    sys.path.insert(0, REF)
+    cv2 = types.ModuleType("cv2")
+    # the single cv2 entry point the post-process chain needs (utils/image.py:56,58)
+    cv2.getAffineTransform = lambda s, d: opost.affine_from_3pts(np.asarray(s), np.asarray(d))
+    sys.modules["cv2"] = cv2
+    sys.modules["seaborn"] = types.ModuleType("seaborn")
+
+    class DCN(torch.nn.Module):
+        """Oracle DCN behind the reference's constructor signature (pose_dla_dcn.py:354)."""
+
+        def __init__(self, chi, cho, kernel_size=(3, 3), stride=1, padding=1, dilation=1,
+                     deformable_groups=1):
+            super().__init__()
+            k = kernel_size[0]
+            self.weight = torch.nn.Parameter(torch.zeros(cho, chi, k, k))
+            self.bias = torch.nn.Parameter(torch.zeros(cho))
+            self.conv_offset_mask = torch.nn.Conv2d(chi, deformable_groups * 3 * k * k, k,
+                                                    stride=stride, padding=padding, bias=True)
+            self.cfg = (stride, padding, dilation, deformable_groups)
+
+        def forward(self, x):
+            return odcn.dcn_module_forward(x, self.weight, self.bias,
+                                           self.conv_offset_mask.weight,
+                                           self.conv_offset_mask.bias, *self.cfg)
+
+    pkg = types.ModuleType("models.networks.DCNv2")
+    pkg.__path__ = []
+    mod = types.ModuleType("models.networks.DCNv2.dcn_v2")
+    mod.DCN = DCN
+    sys.modules["models.networks.DCNv2"] = pkg
+    sys.modules["models.networks.DCNv2.dcn_v2"] = mod
+
+
+_import_reference()
+from models.decode import _nms, _topk, polydet_decode            # noqa: E402
+from models.losses import FocalLoss, RegL1Loss, PolyLoss, WeilPolygonClipper, area  # noqa: E402
+from models.utils import _sigmoid                                 # noqa: E402
+from models.networks.large_hourglass import HourglassNet          # noqa: E402
+from models.networks.pose_dla_dcn import DLASeg                   # noqa: E402
+from utils.post_process import polydet_post_process               # noqa: E402
+
+from cases import (DECODE_CASES, POLY_CASES, HEADS, POST_META, decode_inputs_np,
+                   fill_weights, loss_batch, net_input)  # noqa: E402
+
+T = torch.from_numpy
+
+
+def decode_inputs(*case):
+    return tuple(T(a) for a in decode_inputs_np(*case))
+
+
+def save(name, **arrs):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **arrs)
+    print("wrote %-28s %7.1f KB" % (name + ".npz", os.path.getsize(path) / 1024))
+
+
+# ------------------------------------------------------------------ decode ---
+
+def gen_decode():
+    for case in DECODE_CASES:
+        name, B, C, h, w, N, K, rep = case
+        heat, polys, depth, reg = decode_inputs(*case)
+        nm = _nms(heat)
+        # tie-free requirement: top K+1 of every class distinct and positive
+        v = torch.sort(nm.view(B, C, -1), -1, descending=True)[0][..., :K + 1]
+        assert (v[..., :-1] > v[..., 1:]).all() and (v > 0).all(), "ties in " + name
+        v2 = torch.sort(nm.view(B, -1), -1, descending=True)[0][..., :K + 1]
+        assert (v2[..., :-1] > v2[..., 1:]).all()
+        scores, inds, clses, ys, xs = _topk(nm, K=K)
+        dets = polydet_decode(heat.clone(), polys.clone(), depth.clone(), reg=reg.clone(), K=K, rep=rep)
+        dets_noreg = polydet_decode(heat.clone(), polys.clone(), depth.clone(), reg=None, K=K, rep=rep)
+        save("decode_" + name, nms_sum=nm.double().sum().numpy(), nms_nnz=(nm != 0).sum().numpy(),
+             scores=scores.numpy(), inds=inds.numpy(), clses=clses.numpy(), ys=ys.numpy(),
+             xs=xs.numpy(), dets=dets.numpy(), dets_noreg=dets_noreg.numpy())
+
+
+# ------------------------------------------------------------------ losses ---
+
+class Opt:
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+
+def gen_losses():
+    # sigmoid + focal + RegL1
+    batch, out = loss_batch("base", 2, 32, 48, 16, "cartesian")
+    x = T(out["hm"]).requires_grad_(True)
+    y = _sigmoid(x.clone())
+    loss = FocalLoss()(y, T(batch["hm"]))
+    loss.backward()
+    save("loss_focal", act=y.detach().numpy(), loss=loss.detach().numpy(), grad=x.grad.numpy())
+    # num_pos == 0 branch
+    x0 = T(out["hm"]).requires_grad_(True)
+    l0 = FocalLoss()(_sigmoid(x0.clone()), torch.zeros_like(x0))
+    l0.backward()
+    save("loss_focal_nopos", loss=l0.detach().numpy(), grad=x0.grad.numpy())
+    for key in ("reg", "pseudo_depth"):
+        o = T(out[key]).requires_grad_(True)
+        l = RegL1Loss()(o, T(batch["reg_mask"]), T(batch["ind"]), T(batch[key]))
+        l.backward()
+        save("loss_regl1_" + key, loss=l.detach().numpy(), grad=o.grad.numpy())
+    for name, B, h, w, N, rep, pl, order in POLY_CASES:
+        batch, out = loss_batch(name, B, h, w, N, rep)
+        o = T(out["poly"]).requires_grad_(True)
+        crit = PolyLoss(Opt(poly_loss=pl, rep=rep, poly_order=order))
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            r = crit(o, T(batch["reg_mask"]), T(batch["ind"]), T(batch["poly"]))
+        if order:
+            total = r[0] + r[1]
+            vals = dict(loss=r[0].detach().numpy(), order=r[1].detach().numpy())
+        else:
+            total = r
+            vals = dict(loss=r.detach().numpy())
+        total.backward()
+        g = o.grad
+        # keep only the rows that can be non-zero (object centres) + a checksum of the rest
+        idx = T(batch["ind"])
+        rows = torch.gather(g.view(B, 2 * N, -1), 2, idx.unsqueeze(1).expand(B, 2 * N, idx.shape[1]))
+        save("loss_poly_" + name, grad_rows=rows.numpy(), grad_abs_sum=g.abs().double().sum().numpy(),
+             nobj=batch["reg_mask"].sum(), **vals)
+
+
+def gen_wa_kats():
+    """Known answers of SURVEY.md section 4 / Appendix A, re-measured here."""
+    clip = WeilPolygonClipper(warn_if_empty=False)
+
+    def ngon(n, R, phase=0.0):
+        th = torch.arange(n, dtype=torch.float32) * (2 * math.pi / n) + phase
+        return torch.stack([torch.full((n,), float(R)), th], 1)
+
+    def iou(s, c):
+        cp = clip(s, c)
+        a = area(cp)
+        inter = (a.item() == 0.0) * torch.min(area(s), area(c)) + a
+        return cp, a, inter / (area(c) + area(s) - inter + 1e-6)
+
+    cases = {
+        "same16": (ngon(16, 10), ngon(16, 10)),
+        "inside": (ngon(16, 5), ngon(16, 10)),
+        "rot015": (ngon(16, 10, 0.15), ngon(16, 10)),
+        "contains": (ngon(16, 12), ngon(16, 10)),
+        "tri_vs_16": (torch.tensor([[5, 0.2], [5, 2.3], [5, 4.4]]), ngon(16, 4, 0.05)),
+        "rot_32_vs_16": (ngon(32, 9, 0.07), ngon(16, 10)),
+    }
+    out = {}
+    for k, (s, c) in cases.items():
+        cp, a, v = iou(s, c)
+        out[k + "_subject"] = s.numpy()
+        out[k + "_clip"] = c.numpy()
+        out[k + "_poly"] = cp.numpy()
+        out[k + "_area"] = a.numpy()
+        out[k + "_iou"] = v.numpy()
+        out[k + "_area_subject"] = area(s).numpy()
+    save("wa_kats", **out)
+
+
+# -------------------------------------------------------------------- nets ---
+
+def _fill(model):
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    model.load_state_dict({k: T(v) for k, v in fill_weights(shapes).items()})
+    return shapes
+
+
+def gen_nets():
+    heads = dict(HEADS)
+    x = T(net_input("hourglass"))
+    for ns in (1, 2):
+        torch.manual_seed(0)
+        m = HourglassNet(heads, ns).eval()
+        shapes = _fill(m)
+        with torch.no_grad():
+            outs = m(x)
+        arrs = {"shapes": np.array(json.dumps({k: list(v) for k, v in shapes.items()}))}
+        for s, o in enumerate(outs):
+            for h, v in o.items():
+                arrs["s%d_%s" % (s, h)] = v.numpy()
+        save("net_hourglass%d" % ns, **arrs)
+        del m
+    m = DLASeg("dla34", heads, pretrained=False, down_ratio=4, final_kernel=1, last_level=5,
+               head_conv=256).eval()
+    shapes = _fill(m)
+    xd = T(net_input("dla"))
+    with torch.no_grad():
+        o = m(xd)[0]
+    arrs = {"shapes": np.array(json.dumps({k: list(v) for k, v in shapes.items()}))}
+    for h, v in o.items():
+        arrs["s0_" + h] = v.numpy()
+    save("net_dla34", **arrs)
+
+
+# -------------------------------------------------------------------- post ---
+
+def gen_post():
+    name, B, C, h, w, N, K, rep = DECODE_CASES[0]
+    heat, polys, depth, reg = decode_inputs(*DECODE_CASES[0])
+    dets = polydet_decode(heat, polys, depth, reg=reg, K=K, rep=rep).numpy()[:1]
+    c, s = POST_META["c"], POST_META["s"]
+    ret = polydet_post_process(dets.copy(), [c], [s], h, w, C)
+    arrs = {}
+    for j in range(1, C + 1):
+        arrs["cls%d" % j] = np.array(ret[0][j], dtype=np.float32).reshape(-1, 2 * N + 6)
+    save("post_cart16", **arrs)
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(8)
+    gen_decode()
+    gen_losses()
+    gen_wa_kats()
+    gen_nets()
+    gen_post()
