@@ -1,0 +1,103 @@
+"""ctypes binding of libcenterpoly_hip.so (the C ABI declared in include/centerpoly_hip.h).
+
+There is NO CPU fallback: every op in this package goes through this library and
+raises if it is missing or if a tensor is not on a HIP device.
+"""
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int32, c_int64, c_size_t, c_void_p
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libcenterpoly_hip.so")
+
+CP_OK = 0
+REP = {"cartesian": 0, "polar": 1, "polar_fixed": 2}
+L1_PLAIN, L1_POLAR, L1_POLAR_FIXED, L1_RELU20 = 0, 1, 2, 3
+
+
+class DcnShape(Structure):
+    _fields_ = [(n, c_int32) for n in ("B", "Cin", "H", "W", "Cout", "kh", "kw", "stride", "pad",
+                                       "dil", "deformable_groups")]
+
+
+class NativeLibraryMissing(ImportError):
+    pass
+
+
+class NativeError(RuntimeError):
+    pass
+
+
+_lib = None
+
+_P = c_void_p
+_SIGNATURES = {
+    "cp_abi_version": (c_int32, []),
+    "cp_strerror": (c_char_p, [c_int32]),
+    "cp_build_arch": (c_char_p, []),
+    "cp_dcn_v2_forward": (c_int32, [POINTER(DcnShape), _P, _P, c_int64, _P, c_int64, c_int32, _P, _P,
+                                    _P, _P, c_int32, _P, _P]),
+    "cp_dcn_v2_backward_workspace_bytes": (c_size_t, [POINTER(DcnShape)]),
+    "cp_dcn_v2_backward": (c_int32, [POINTER(DcnShape), _P, _P, c_int64, _P, c_int64, c_int32, _P, _P,
+                                     _P, _P, c_int64, _P, c_int64, _P, _P, _P, c_size_t, _P]),
+    "cp_polydet_decode_workspace_bytes": (c_size_t, [c_int32] * 5),
+    "cp_polydet_decode": (c_int32, [_P, _P, _P, _P] + [c_int32] * 7 + [_P, _P, _P, _P, c_size_t, _P]),
+    "cp_sigmoid_focal_workspace_bytes": (c_size_t, [c_int64]),
+    "cp_sigmoid_focal_forward": (c_int32, [_P, _P, c_int64, _P, _P, _P, c_size_t, _P]),
+    "cp_sigmoid_focal_backward": (c_int32, [_P, _P, c_int64, _P, _P, _P, _P]),
+    "cp_gather_l1_forward": (c_int32, [_P, _P, _P, _P, _P] + [c_int32] * 6 + [c_float, _P, _P]),
+    "cp_gather_l1_backward": (c_int32, [_P, _P, _P, _P, _P] + [c_int32] * 6 + [c_float, _P, _P, _P]),
+    "cp_poly_iou_order_workspace_bytes": (c_size_t, [c_int32] * 3),
+    "cp_poly_iou_order_forward": (c_int32, [_P, _P, _P, _P] + [c_int32] * 6 + [_P, _P, _P, _P,
+                                                                               c_size_t, _P]),
+    "cp_poly_iou_order_backward": (c_int32, [_P, _P, _P, _P] + [c_int32] * 6 + [_P, _P, _P, _P,
+                                                                                c_size_t, _P]),
+}
+
+EXPORTS = tuple(_SIGNATURES)
+
+
+def lib():
+    """The loaded library; raises NativeLibraryMissing when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise NativeLibraryMissing(
+                "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(or `make -C centerpoly_amd/csrc`). centerpoly_amd has no CPU fallback." % LIB_PATH)
+        l = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(l, name)
+            fn.restype = res
+            fn.argtypes = args
+        if l.cp_abi_version() != 1:
+            raise NativeError("ABI version mismatch")
+        _lib = l
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != CP_OK:
+        raise NativeError("%s failed: %s (%d)" % (what, lib().cp_strerror(rc).decode(), rc))
+
+
+def ptr(t):
+    """Device pointer of a tensor (or NULL).  Refuses host tensors and non-contiguous views."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise NativeError("centerpoly_amd ops need HIP device tensors (got %s); there is no CPU "
+                          "fallback" % t.device)
+    if not t.is_contiguous():
+        raise NativeError("tensor must be contiguous")
+    return c_void_p(t.data_ptr())
+
+
+def stream():
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def workspace(nbytes, device):
+    return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)

@@ -1,0 +1,147 @@
+"""BaseDetector (reference: src/lib/detectors/base_detector.py:18-191).
+
+Same surface: BaseDetector(opt); .pre_process(image, scale, meta) -> (images, meta);
+.run(image_or_path_or_tensor) -> {'results', 'tot','load','pre','net','dec','post','merge'}.
+The accelerated path is GPU-only: opt.gpus = [-1] raises instead of silently
+running on the host.  cv2 is not required: the affine warp of pre_process is a
+numpy bilinear inverse map (zero border), a .npy path or ndarray is accepted as
+the image source, and `opt.load_model == ''` keeps the random initialisation
+(the reference calls torch.load unconditionally, :27).
+"""
+import time
+
+import numpy as np
+import torch
+
+from ..models.model import create_model, load_model
+from ..utils.image import get_affine_transform
+
+
+def _resize_bilinear(img, new_w, new_h):
+    h, w = img.shape[:2]
+    if (w, h) == (new_w, new_h):
+        return img
+    t = torch.from_numpy(np.ascontiguousarray(img)).permute(2, 0, 1)[None].float()
+    t = torch.nn.functional.interpolate(t, size=(new_h, new_w), mode="bilinear", align_corners=False)
+    return t[0].permute(1, 2, 0).numpy()
+
+
+def _warp_affine(img, trans, out_w, out_h):
+    """dst(x,y) = src(M^-1 [x,y,1]) with bilinear taps and zero border."""
+    M = np.vstack([trans, [0, 0, 1]])
+    Minv = np.linalg.inv(M)[:2]
+    xs, ys = np.meshgrid(np.arange(out_w, dtype=np.float64), np.arange(out_h, dtype=np.float64))
+    sx = Minv[0, 0] * xs + Minv[0, 1] * ys + Minv[0, 2]
+    sy = Minv[1, 0] * xs + Minv[1, 1] * ys + Minv[1, 2]
+    x0, y0 = np.floor(sx).astype(np.int64), np.floor(sy).astype(np.int64)
+    fx, fy = (sx - x0)[..., None], (sy - y0)[..., None]
+    h, w = img.shape[:2]
+    src = img.astype(np.float32)
+
+    def tap(yy, xx):
+        ok = (yy >= 0) & (yy < h) & (xx >= 0) & (xx < w)
+        v = src[np.clip(yy, 0, h - 1), np.clip(xx, 0, w - 1)]
+        return v * ok[..., None]
+
+    out = (1 - fy) * ((1 - fx) * tap(y0, x0) + fx * tap(y0, x0 + 1)) \
+        + fy * ((1 - fx) * tap(y0 + 1, x0) + fx * tap(y0 + 1, x0 + 1))
+    return out.astype(np.float32)
+
+
+class BaseDetector(object):
+    def __init__(self, opt):
+        if opt.gpus[0] < 0:
+            raise RuntimeError("centerpoly_amd detectors run on a HIP device only (--gpus -1 "
+                               "has no CPU fallback)")
+        opt.device = torch.device("cuda")
+        print("Creating model...")
+        self.model = create_model(opt.arch, opt.heads, opt.head_conv)
+        if getattr(opt, "load_model", ""):
+            self.model = load_model(self.model, opt.load_model)
+        self.model = self.model.to(opt.device)
+        self.model.eval()
+        self.mean = np.array(opt.mean, dtype=np.float32).reshape(1, 1, 3)
+        self.std = np.array(opt.std, dtype=np.float32).reshape(1, 1, 3)
+        self.max_per_image = opt.K
+        self.num_classes = opt.num_classes
+        self.scales = opt.test_scales
+        self.opt = opt
+        self.pause = True
+
+    def pre_process(self, image, scale, meta=None):
+        height, width = image.shape[0:2]
+        new_height, new_width = int(height * scale), int(width * scale)
+        if self.opt.fix_res:
+            inp_height, inp_width = self.opt.input_h, self.opt.input_w
+            c = np.array([new_width / 2.0, new_height / 2.0], dtype=np.float32)
+            s = max(height, width) * 1.0
+        else:
+            inp_height = (new_height | self.opt.pad) + 1
+            inp_width = (new_width | self.opt.pad) + 1
+            c = np.array([new_width // 2, new_height // 2], dtype=np.float32)
+            s = np.array([inp_width, inp_height], dtype=np.float32)
+        trans_input = get_affine_transform(c, s, 0, [inp_width, inp_height])
+        resized = _resize_bilinear(image, new_width, new_height)
+        inp = _warp_affine(resized, trans_input, inp_width, inp_height)
+        inp = ((inp / 255.0 - self.mean) / self.std).astype(np.float32)
+        images = inp.transpose(2, 0, 1).reshape(1, 3, inp_height, inp_width)
+        if self.opt.flip_test:
+            images = np.concatenate((images, images[:, :, :, ::-1]), axis=0)
+        images = torch.from_numpy(np.ascontiguousarray(images))
+        meta = {"c": c, "s": s, "out_height": inp_height // self.opt.down_ratio,
+                "out_width": inp_width // self.opt.down_ratio}
+        return images, meta
+
+    def process(self, images, return_time=False):
+        raise NotImplementedError
+
+    def post_process(self, dets, meta, scale=1, fg=None):
+        raise NotImplementedError
+
+    def merge_outputs(self, detections):
+        raise NotImplementedError
+
+    def run(self, image_or_path_or_tensor, id=1, meta=None):
+        load_time = pre_time = net_time = dec_time = post_time = merge_time = 0
+        start_time = time.time()
+        pre_processed = False
+        if isinstance(image_or_path_or_tensor, np.ndarray):
+            image = image_or_path_or_tensor
+        elif isinstance(image_or_path_or_tensor, str):
+            image = np.load(image_or_path_or_tensor)
+        else:
+            image = image_or_path_or_tensor["image"][0].numpy()
+            pre_processed_images = image_or_path_or_tensor
+            pre_processed = True
+        loaded_time = time.time()
+        load_time += loaded_time - start_time
+
+        detections = []
+        for scale in self.scales:
+            scale_start_time = time.time()
+            if not pre_processed:
+                images, meta = self.pre_process(image, scale, meta)
+            else:
+                images = pre_processed_images["images"][scale][0]
+                meta = pre_processed_images["meta"][scale]
+                meta = {k: v.numpy()[0] for k, v in meta.items()}
+            images = images.to(self.opt.device)
+            torch.cuda.synchronize()
+            pre_process_time = time.time()
+            pre_time += pre_process_time - scale_start_time
+            output, dets, forward_time = self.process(images, return_time=True)
+            torch.cuda.synchronize()
+            net_time += forward_time - pre_process_time
+            decode_time = time.time()
+            dec_time += decode_time - forward_time
+            dets = self.post_process(dets, meta, scale)
+            post_process_time = time.time()
+            post_time += post_process_time - decode_time
+            detections.append(dets)
+
+        results = self.merge_outputs(detections)
+        end_time = time.time()
+        merge_time += end_time - post_process_time
+        return {"results": results, "tot": end_time - start_time, "load": load_time,
+                "pre": pre_time, "net": net_time, "dec": dec_time, "post": post_time,
+                "merge": merge_time}

@@ -1,0 +1,125 @@
+"""`DCN` -- the plugin slot the reference imports as `from .DCNv2.dcn_v2 import DCN`
+(src/lib/models/networks/pose_dla_dcn.py:16, constructed at :354 and at
+src/lib/models/networks/resnet_dcn.py:221).  Upstream (CharlesShang/DCNv2) is
+absent from the reference tree; parameter names (`weight`, `bias`,
+`conv_offset_mask.{weight,bias}`) are fixed by the published checkpoints.
+
+forward = conv_offset_mask (dense 3x3 conv) -> ONE fused HIP kernel that reads the
+raw 27-channel tensor (offsets + mask logits, sigmoid applied in-kernel), samples,
+modulates and contracts on the matrix cores.  No chunk/cat/sigmoid/im2col tensors.
+"""
+import math
+
+import torch
+import torch.nn as nn
+from torch.nn.modules.utils import _pair
+
+from .... import _C
+
+
+def _shape(x, weight, stride, pad, dil, dg):
+    s = _C.DcnShape()
+    s.B, s.Cin, s.H, s.W = x.shape
+    s.Cout, _, s.kh, s.kw = weight.shape
+    s.stride, s.pad, s.dil, s.deformable_groups = stride, pad, dil, dg
+    return s
+
+
+def dcn_v2_forward_raw(x, om, weight, bias, stride=1, pad=1, dil=1, dg=1, ep_scale=None,
+                       ep_shift=None, relu=False):
+    """Forward on the raw offset/mask tensor `om` [B, 3*kh*kw, Ho, Wo] (mask as logits).
+    Optional fused per-channel epilogue out = act(acc*ep_scale + ep_shift)."""
+    L = _C.lib()
+    s = _shape(x, weight, stride, pad, dil, dg)
+    K = s.kh * s.kw
+    Ho, Wo = om.shape[2], om.shape[3]
+    out = torch.empty((s.B, s.Cout, Ho, Wo), dtype=torch.float32, device=x.device)
+    bs = 3 * K * Ho * Wo
+    mask_ptr = _C.c_void_p(om.data_ptr() + 4 * 2 * K * Ho * Wo)
+    rc = L.cp_dcn_v2_forward(s, _C.ptr(x), _C.ptr(om), bs, mask_ptr, bs, 1, _C.ptr(weight),
+                             _C.ptr(bias), _C.ptr(ep_scale), _C.ptr(ep_shift), 1 if relu else 0,
+                             _C.ptr(out), _C.stream())
+    _C.check(rc, "cp_dcn_v2_forward")
+    return out
+
+
+class _DCNv2Function(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, om, weight, bias, stride, pad, dil, dg):
+        for t in (x, om, weight):
+            if t.dtype != torch.float32:
+                raise _C.NativeError("DCN expects float32")
+        x, om, weight = x.contiguous(), om.contiguous(), weight.contiguous()
+        ctx.cfg = (stride, pad, dil, dg)
+        ctx.save_for_backward(x, om, weight)
+        ctx.has_bias = bias is not None
+        return dcn_v2_forward_raw(x, om, weight, bias, stride, pad, dil, dg)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        x, om, weight = ctx.saved_tensors
+        stride, pad, dil, dg = ctx.cfg
+        L = _C.lib()
+        s = _shape(x, weight, stride, pad, dil, dg)
+        K = s.kh * s.kw
+        Ho, Wo = om.shape[2], om.shape[3]
+        grad_out = grad_out.contiguous()
+        gx = torch.zeros_like(x)
+        gom = torch.empty_like(om)
+        gw = torch.zeros_like(weight)
+        gb = torch.zeros((s.Cout,), dtype=torch.float32, device=x.device)
+        bs = 3 * K * Ho * Wo
+        off_m = 4 * 2 * K * Ho * Wo
+        ws = _C.workspace(L.cp_dcn_v2_backward_workspace_bytes(s), x.device)
+        rc = L.cp_dcn_v2_backward(s, _C.ptr(x), _C.ptr(om), bs, _C.c_void_p(om.data_ptr() + off_m),
+                                  bs, 1, _C.ptr(weight), _C.ptr(grad_out), _C.ptr(gx), _C.ptr(gom),
+                                  bs, _C.c_void_p(gom.data_ptr() + off_m), bs, _C.ptr(gw),
+                                  _C.ptr(gb), _C.ptr(ws), ws.numel(), _C.stream())
+        _C.check(rc, "cp_dcn_v2_backward")
+        return gx, gom, gw, (gb if ctx.has_bias else None), None, None, None, None
+
+
+class DCN(nn.Module):
+    """DCN(in_channels, out_channels, kernel_size, stride, padding, dilation=1,
+    deformable_groups=1): forward(x[B,Cin,H,W]) -> [B,Cout,Ho,Wo]."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride, padding, dilation=1,
+                 deformable_groups=1):
+        super(DCN, self).__init__()
+        self.in_channels = in_channels
+        self.out_channels = out_channels
+        self.kernel_size = _pair(kernel_size)
+        self.stride = stride if isinstance(stride, int) else stride[0]
+        self.padding = padding if isinstance(padding, int) else padding[0]
+        self.dilation = dilation if isinstance(dilation, int) else dilation[0]
+        self.deformable_groups = deformable_groups
+        self.weight = nn.Parameter(torch.empty(out_channels, in_channels, *self.kernel_size))
+        self.bias = nn.Parameter(torch.empty(out_channels))
+        kh, kw = self.kernel_size
+        self.conv_offset_mask = nn.Conv2d(in_channels, deformable_groups * 3 * kh * kw,
+                                          kernel_size=self.kernel_size, stride=self.stride,
+                                          padding=self.padding, bias=True)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        n = self.in_channels * self.kernel_size[0] * self.kernel_size[1]
+        stdv = 1.0 / math.sqrt(n)
+        with torch.no_grad():
+            self.weight.uniform_(-stdv, stdv)
+            self.bias.zero_()
+            # zero offsets / mask logits at construction: DCN(x) == 0.5*conv(x, W) + b
+            self.conv_offset_mask.weight.zero_()
+            self.conv_offset_mask.bias.zero_()
+
+    def forward(self, x):
+        om = self.conv_offset_mask(x)
+        return _DCNv2Function.apply(x, om, self.weight, self.bias, self.stride, self.padding,
+                                    self.dilation, self.deformable_groups)
+
+    def forward_fused(self, x, ep_scale, ep_shift, relu=True):
+        """Inference: DCN + per-channel affine (folded BatchNorm, bias included) + ReLU
+        in the kernel's epilogue (replaces DeformConv.forward's three passes)."""
+        om = self.conv_offset_mask(x)
+        return dcn_v2_forward_raw(x.contiguous(), om.contiguous(), self.weight, None, self.stride,
+                                  self.padding, self.dilation, self.deformable_groups, ep_scale,
+                                  ep_shift, relu)

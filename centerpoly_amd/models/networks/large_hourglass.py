@@ -1,0 +1,155 @@
+"""Stacked Hourglass (Hourglass-104) with the polydet heads.
+
+Same constructor surface and state_dict key grammar as the live classes of the
+reference's src/lib/models/networks/large_hourglass.py (convolution :24-37,
+residual :55-81, kp_module :283-342, exkp :345-462, HourglassNet :471-484):
+`pre.*`, `kps.s.{up1,low1,low2,low3}.*`, `cnvs.s.*`, `inters.*`, `inters_.*`,
+`cnvs_.*`, heads `{head}.s.0.conv.*` / `{head}.s.1.*`.  The dead U-Net / SqEx
+classes of that file are not part of the hot path and are not restated.
+Pooling is replaced by stride-2 residuals and up-sampling is nearest x2, as in
+the reference.  No DCN here: every layer is a dense convolution.
+"""
+import torch
+import torch.nn as nn
+
+
+class convolution(nn.Module):
+    def __init__(self, k, inp_dim, out_dim, stride=1, with_bn=True):
+        super().__init__()
+        pad = (k - 1) // 2
+        self.conv = nn.Conv2d(inp_dim, out_dim, (k, k), padding=(pad, pad), stride=(stride, stride),
+                              bias=not with_bn)
+        self.bn = nn.BatchNorm2d(out_dim) if with_bn else nn.Sequential()
+        self.relu = nn.ReLU(inplace=True)
+
+    def forward(self, x):
+        return self.relu(self.bn(self.conv(x)))
+
+
+class residual(nn.Module):
+    def __init__(self, k, inp_dim, out_dim, stride=1, with_bn=True):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inp_dim, out_dim, (3, 3), padding=(1, 1), stride=(stride, stride),
+                               bias=False)
+        self.bn1 = nn.BatchNorm2d(out_dim)
+        self.relu1 = nn.ReLU(inplace=True)
+        self.conv2 = nn.Conv2d(out_dim, out_dim, (3, 3), padding=(1, 1), bias=False)
+        self.bn2 = nn.BatchNorm2d(out_dim)
+        needs_proj = stride != 1 or inp_dim != out_dim
+        self.skip = nn.Sequential(
+            nn.Conv2d(inp_dim, out_dim, (1, 1), stride=(stride, stride), bias=False),
+            nn.BatchNorm2d(out_dim)) if needs_proj else nn.Sequential()
+        self.relu = nn.ReLU(inplace=True)
+
+    def forward(self, x):
+        y = self.relu1(self.bn1(self.conv1(x)))
+        y = self.bn2(self.conv2(y))
+        return self.relu(y + self.skip(x))
+
+
+def _stack(first, rest_dim, count, tail=None):
+    """`count` residuals; `first` and optional `tail` are given, the middle ones keep rest_dim."""
+    layers = [first] + [residual(3, rest_dim, rest_dim) for _ in range(count - 1)]
+    if tail is not None:
+        layers[-1] = tail
+    return nn.Sequential(*layers)
+
+
+def make_layer(k, inp_dim, out_dim, modules, layer=residual, **kw):
+    return _stack(layer(k, inp_dim, out_dim, **kw), out_dim, modules)
+
+
+def make_layer_revr(k, inp_dim, out_dim, modules, layer=residual, **kw):
+    layers = [layer(k, inp_dim, inp_dim, **kw) for _ in range(modules - 1)]
+    layers.append(layer(k, inp_dim, out_dim, **kw))
+    return nn.Sequential(*layers)
+
+
+def make_hg_layer(k, dim0, dim1, mod, layer=residual, **kw):
+    """First residual has stride 2 (replaces max-pooling, reference :465-468)."""
+    return _stack(layer(k, dim0, dim1, stride=2), dim1, mod)
+
+
+class MergeUp(nn.Module):
+    def forward(self, up1, up2):
+        return up1 + up2
+
+
+def make_kp_layer(cnv_dim, curr_dim, out_dim):
+    return nn.Sequential(convolution(3, cnv_dim, curr_dim, with_bn=False),
+                         nn.Conv2d(curr_dim, out_dim, (1, 1)))
+
+
+make_poly_layer = make_kp_layer
+
+
+class kp_module(nn.Module):
+    def __init__(self, n, dims, modules):
+        super().__init__()
+        self.n = n
+        curr_mod, next_mod = modules[0], modules[1]
+        curr_dim, next_dim = dims[0], dims[1]
+        self.up1 = make_layer(3, curr_dim, curr_dim, curr_mod)
+        self.max1 = nn.Sequential()
+        self.low1 = make_hg_layer(3, curr_dim, next_dim, curr_mod)
+        self.low2 = kp_module(n - 1, dims[1:], modules[1:]) if n > 1 else \
+            make_layer(3, next_dim, next_dim, next_mod)
+        self.low3 = make_layer_revr(3, next_dim, curr_dim, curr_mod)
+        self.up2 = nn.Upsample(scale_factor=2)
+        self.merge = MergeUp()
+
+    def forward(self, x):
+        up1 = self.up1(x)
+        low = self.low3(self.low2(self.low1(self.max1(x))))
+        return self.merge(up1, self.up2(low))
+
+
+class exkp(nn.Module):
+    def __init__(self, n, nstack, dims, modules, heads, cnv_dim=256):
+        super().__init__()
+        self.nstack = nstack
+        self.heads = heads
+        curr_dim = dims[0]
+        self.pre = nn.Sequential(convolution(7, 3, 128, stride=2), residual(3, 128, 256, stride=2))
+        self.kps = nn.ModuleList([kp_module(n, dims, modules) for _ in range(nstack)])
+        self.cnvs = nn.ModuleList([convolution(3, curr_dim, cnv_dim) for _ in range(nstack)])
+        self.inters = nn.ModuleList([residual(3, curr_dim, curr_dim) for _ in range(nstack - 1)])
+        self.inters_ = nn.ModuleList([
+            nn.Sequential(nn.Conv2d(curr_dim, curr_dim, (1, 1), bias=False),
+                          nn.BatchNorm2d(curr_dim)) for _ in range(nstack - 1)])
+        self.cnvs_ = nn.ModuleList([
+            nn.Sequential(nn.Conv2d(cnv_dim, curr_dim, (1, 1), bias=False),
+                          nn.BatchNorm2d(curr_dim)) for _ in range(nstack - 1)])
+        for head in heads.keys():
+            module = nn.ModuleList([make_kp_layer(cnv_dim, curr_dim, heads[head])
+                                    for _ in range(nstack)])
+            self.__setattr__(head, module)
+            if "hm" in head:
+                for heat in module:
+                    heat[-1].bias.data.fill_(-2.19)
+        self.relu = nn.ReLU(inplace=True)
+
+    def forward(self, image):
+        inter = self.pre(image)
+        outs = []
+        for s in range(self.nstack):
+            cnv = self.cnvs[s](self.kps[s](inter))
+            outs.append({head: getattr(self, head)[s](cnv) for head in self.heads})
+            if s < self.nstack - 1:
+                inter = self.relu(self.inters_[s](inter) + self.cnvs_[s](cnv))
+                inter = self.inters[s](inter)
+        return outs
+
+
+class HourglassNet(exkp):
+    def __init__(self, heads, num_stacks=2):
+        super().__init__(5, num_stacks, [256, 256, 384, 384, 384, 512], [2, 2, 2, 2, 2, 4], heads,
+                         cnv_dim=256)
+
+
+def get_large_hourglass_net(num_layers, heads, head_conv):
+    return HourglassNet(heads, 2)
+
+
+def get_small_hourglass_net(num_layers, heads, head_conv):
+    return HourglassNet(heads, 1)

@@ -1,0 +1,267 @@
+"""DLA-34 backbone with DCNv2 up-sampling and the polydet heads.
+
+Same public surface and the same state_dict key grammar as the reference's
+src/lib/models/networks/pose_dla_dcn.py (DLA :225-308, BasicBlock :32-60, Root
+:148-166, Tree :169-222, DeformConv :347-359, IDAUp :362-387, DLAUp :390-413,
+DLASeg :427-482, get_pose_net :485-492), so published checkpoints load
+unchanged.  Differences, all deliberate:
+  * `pretrained` defaults to False and never touches the network (the reference
+    forces an ImageNet URL fetch, :485-491);
+  * in eval mode DeformConv runs DCN + BatchNorm + ReLU as ONE kernel (BN folded
+    into the DCN epilogue) instead of three passes over the feature map.
+"""
+import math
+
+import numpy as np
+import torch
+from torch import nn
+
+from .DCNv2.dcn_v2 import DCN
+
+BN_MOMENTUM = 0.1
+
+
+def _bn(c):
+    return nn.BatchNorm2d(c, momentum=BN_MOMENTUM)
+
+
+class BasicBlock(nn.Module):
+    def __init__(self, inplanes, planes, stride=1, dilation=1):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, 3, stride, dilation, dilation, bias=False)
+        self.bn1 = _bn(planes)
+        self.relu = nn.ReLU(inplace=True)
+        self.conv2 = nn.Conv2d(planes, planes, 3, 1, dilation, dilation, bias=False)
+        self.bn2 = _bn(planes)
+        self.stride = stride
+
+    def forward(self, x, residual=None):
+        skip = x if residual is None else residual
+        y = self.relu(self.bn1(self.conv1(x)))
+        y = self.bn2(self.conv2(y))
+        y += skip
+        return self.relu(y)
+
+
+class Root(nn.Module):
+    def __init__(self, in_channels, out_channels, kernel_size, residual):
+        super().__init__()
+        self.conv = nn.Conv2d(in_channels, out_channels, 1, 1, (kernel_size - 1) // 2, bias=False)
+        self.bn = _bn(out_channels)
+        self.relu = nn.ReLU(inplace=True)
+        self.residual = residual
+
+    def forward(self, *xs):
+        y = self.bn(self.conv(torch.cat(xs, 1)))
+        if self.residual:
+            y += xs[0]
+        return self.relu(y)
+
+
+class Tree(nn.Module):
+    """Hierarchical aggregation node: two sub-trees (or two blocks at the leaves)
+    whose outputs, plus optional passed-down children, meet in a 1x1 Root."""
+
+    def __init__(self, levels, block, in_channels, out_channels, stride=1, level_root=False,
+                 root_dim=0, root_kernel_size=1, dilation=1, root_residual=False):
+        super().__init__()
+        root_dim = root_dim or 2 * out_channels
+        if level_root:
+            root_dim += in_channels
+        self.levels, self.level_root, self.root_dim = levels, level_root, root_dim
+        if levels == 1:
+            self.tree1 = block(in_channels, out_channels, stride, dilation=dilation)
+            self.tree2 = block(out_channels, out_channels, 1, dilation=dilation)
+            self.root = Root(root_dim, out_channels, root_kernel_size, root_residual)
+        else:
+            kw = dict(root_kernel_size=root_kernel_size, dilation=dilation,
+                      root_residual=root_residual)
+            self.tree1 = Tree(levels - 1, block, in_channels, out_channels, stride, root_dim=0, **kw)
+            self.tree2 = Tree(levels - 1, block, out_channels, out_channels,
+                              root_dim=root_dim + out_channels, **kw)
+        self.downsample = nn.MaxPool2d(stride, stride=stride) if stride > 1 else None
+        self.project = None
+        if in_channels != out_channels:
+            self.project = nn.Sequential(nn.Conv2d(in_channels, out_channels, 1, 1, bias=False),
+                                         _bn(out_channels))
+
+    def forward(self, x, residual=None, children=None):
+        children = [] if children is None else children
+        bottom = x if self.downsample is None else self.downsample(x)
+        residual = bottom if self.project is None else self.project(bottom)
+        if self.level_root:
+            children.append(bottom)
+        x1 = self.tree1(x, residual)
+        if self.levels == 1:
+            return self.root(self.tree2(x1), x1, *children)
+        children.append(x1)
+        return self.tree2(x1, children=children)
+
+
+class DLA(nn.Module):
+    def __init__(self, levels, channels, num_classes=1000, block=BasicBlock, residual_root=False,
+                 linear_root=False):
+        super().__init__()
+        self.channels, self.num_classes = channels, num_classes
+        c = channels
+        self.base_layer = nn.Sequential(nn.Conv2d(3, c[0], 7, 1, 3, bias=False), _bn(c[0]),
+                                        nn.ReLU(inplace=True))
+        self.level0 = self._conv_level(c[0], c[0], levels[0])
+        self.level1 = self._conv_level(c[0], c[1], levels[1], stride=2)
+        for i in range(2, 6):
+            setattr(self, "level%d" % i, Tree(levels[i], block, c[i - 1], c[i], 2,
+                                              level_root=i > 2, root_residual=residual_root))
+
+    @staticmethod
+    def _conv_level(inplanes, planes, convs, stride=1, dilation=1):
+        mods = []
+        for i in range(convs):
+            mods += [nn.Conv2d(inplanes, planes, 3, stride if i == 0 else 1, dilation, dilation,
+                               bias=False), _bn(planes), nn.ReLU(inplace=True)]
+            inplanes = planes
+        return nn.Sequential(*mods)
+
+    def forward(self, x):
+        x = self.base_layer(x)
+        pyramid = []
+        for i in range(6):
+            x = getattr(self, "level%d" % i)(x)
+            pyramid.append(x)
+        return pyramid
+
+    def load_pretrained_model(self, data="imagenet", name="dla34", hash="ba72cf86"):
+        """Offline only: `data + name` must be a local .pth (the reference downloads)."""
+        if not name.endswith(".pth"):
+            raise RuntimeError("no network: pass a local ImageNet checkpoint as name='*.pth'")
+        weights = torch.load(data + name, map_location="cpu")
+        self.load_state_dict(weights, strict=False)
+
+
+def dla34(pretrained=False, **kwargs):
+    model = DLA([1, 1, 1, 2, 2, 1], [16, 32, 64, 128, 256, 512], block=BasicBlock, **kwargs)
+    if pretrained:
+        model.load_pretrained_model(data="imagenet", name="dla34", hash="ba72cf86")
+    return model
+
+
+def fill_up_weights(up):
+    """Bilinear kernel for the depth-wise transposed conv (reference :335-344)."""
+    w = up.weight.data
+    k = w.size(2)
+    f = math.ceil(k / 2)
+    c = (2 * f - 1 - f % 2) / (2.0 * f)
+    tri = torch.tensor([1 - abs(i / f - c) for i in range(k)], dtype=w.dtype)
+    w[:, 0] = torch.outer(tri, tri[:w.size(3)])
+
+
+def fill_fc_weights(layers):
+    for m in layers.modules():
+        if isinstance(m, nn.Conv2d) and m.bias is not None:
+            nn.init.constant_(m.bias, 0)
+
+
+class DeformConv(nn.Module):
+    """ReLU(BN(DCN(x))) (reference :347-359)."""
+
+    def __init__(self, chi, cho):
+        super().__init__()
+        self.actf = nn.Sequential(_bn(cho), nn.ReLU(inplace=True))
+        self.conv = DCN(chi, cho, kernel_size=(3, 3), stride=1, padding=1, dilation=1,
+                        deformable_groups=1)
+
+    def folded_affine(self):
+        bn = self.actf[0]
+        scale = bn.weight * torch.rsqrt(bn.running_var + bn.eps)
+        shift = (self.conv.bias - bn.running_mean) * scale + bn.bias
+        return scale.contiguous(), shift.contiguous()
+
+    def forward(self, x):
+        if not self.training and not torch.is_grad_enabled():
+            scale, shift = self.folded_affine()
+            return self.conv.forward_fused(x, scale, shift, relu=True)
+        return self.actf(self.conv(x))
+
+
+class IDAUp(nn.Module):
+    def __init__(self, o, channels, up_f):
+        super().__init__()
+        for i in range(1, len(channels)):
+            f = int(up_f[i])
+            up = nn.ConvTranspose2d(o, o, f * 2, stride=f, padding=f // 2, output_padding=0,
+                                    groups=o, bias=False)
+            fill_up_weights(up)
+            setattr(self, "proj_%d" % i, DeformConv(channels[i], o))
+            setattr(self, "up_%d" % i, up)
+            setattr(self, "node_%d" % i, DeformConv(o, o))
+
+    def forward(self, layers, startp, endp):
+        for i in range(startp + 1, endp):
+            k = i - startp
+            up = getattr(self, "up_%d" % k)(getattr(self, "proj_%d" % k)(layers[i]))
+            layers[i] = getattr(self, "node_%d" % k)(up + layers[i - 1])
+
+
+class DLAUp(nn.Module):
+    def __init__(self, startp, channels, scales, in_channels=None):
+        super().__init__()
+        self.startp = startp
+        in_channels = list(channels) if in_channels is None else in_channels
+        self.channels = channels
+        channels = list(channels)
+        scales = np.array(scales, dtype=int)
+        for i in range(len(channels) - 1):
+            j = -i - 2
+            setattr(self, "ida_%d" % i, IDAUp(channels[j], in_channels[j:], scales[j:] // scales[j]))
+            scales[j + 1:] = scales[j]
+            in_channels[j + 1:] = [channels[j] for _ in channels[j + 1:]]
+
+    def forward(self, layers):
+        out = [layers[-1]]
+        for i in range(len(layers) - self.startp - 1):
+            getattr(self, "ida_%d" % i)(layers, len(layers) - i - 2, len(layers))
+            out.insert(0, layers[-1])
+        return out
+
+
+class DLASeg(nn.Module):
+    def __init__(self, base_name, heads, pretrained, down_ratio, final_kernel, last_level,
+                 head_conv, out_channel=0):
+        super().__init__()
+        assert down_ratio in [2, 4, 8, 16]
+        self.first_level = int(np.log2(down_ratio))
+        self.last_level = last_level
+        self.base = globals()[base_name](pretrained=pretrained)
+        channels = self.base.channels
+        fl = self.first_level
+        scales = [2 ** i for i in range(len(channels[fl:]))]
+        self.dla_up = DLAUp(fl, channels[fl:], scales)
+        out_channel = out_channel or channels[fl]
+        self.ida_up = IDAUp(out_channel, channels[fl:last_level],
+                            [2 ** i for i in range(last_level - fl)])
+        self.heads = heads
+        for head, classes in heads.items():
+            if head_conv > 0:
+                fc = nn.Sequential(
+                    nn.Conv2d(channels[fl], head_conv, 3, padding=1, bias=True),
+                    nn.ReLU(inplace=True),
+                    nn.Conv2d(head_conv, classes, final_kernel, 1, final_kernel // 2, bias=True))
+                last = fc[-1]
+            else:
+                fc = nn.Conv2d(channels[fl], classes, final_kernel, 1, final_kernel // 2, bias=True)
+                last = fc
+            if "hm" in head:
+                last.bias.data.fill_(-2.19)
+            else:
+                fill_fc_weights(fc)
+            self.__setattr__(head, fc)
+
+    def forward(self, x):
+        x = self.dla_up(self.base(x))
+        y = [x[i].clone() for i in range(self.last_level - self.first_level)]
+        self.ida_up(y, 0, len(y))
+        return [{head: getattr(self, head)(y[-1]) for head in self.heads}]
+
+
+def get_pose_net(num_layers, heads, head_conv=256, down_ratio=4, pretrained=False):
+    return DLASeg("dla{}".format(num_layers), heads, pretrained=pretrained, down_ratio=down_ratio,
+                  final_kernel=1, last_level=5, head_conv=head_conv)

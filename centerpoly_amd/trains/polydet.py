@@ -1,0 +1,95 @@
+"""PolydetLoss / PolydetTrainer (reference: src/lib/trains/polydet.py:20-237).
+
+Aggregation, weights, returned stats keys and the in-place activation of
+output['hm'] follow the reference; every term is a HIP kernel and stays a device
+scalar.  Switches outside the accelerated path (mse_loss, eval_oracle_*,
+cat_spec_poly, dense_poly; reference :49-70,103-111, all default off) raise.
+"""
+import torch
+
+from ..models.decode import polydet_decode
+from ..models.losses import FocalLoss, PolyLoss, RegL1Loss, sigmoid_focal_loss
+from ..utils.post_process import polydet_post_process
+from .base_trainer import BaseTrainer
+
+_UNSUPPORTED = ("mse_loss", "eval_oracle_hm", "eval_oracle_border_hm", "eval_oracle_offset",
+                "eval_oracle_poly", "eval_oracle_pseudo_depth", "cat_spec_poly", "dense_poly")
+
+
+class PolydetLoss(torch.nn.Module):
+    def __init__(self, opt):
+        super(PolydetLoss, self).__init__()
+        for flag in _UNSUPPORTED:
+            if getattr(opt, flag, False):
+                raise NotImplementedError("--%s is outside the accelerated polydet path" % flag)
+        if getattr(opt, "reg_loss", "l1") != "l1":
+            raise NotImplementedError("only --reg_loss l1 is accelerated")
+        self.crit = FocalLoss()
+        self.crit_reg = RegL1Loss()
+        self.crit_poly = PolyLoss(opt)
+        self.opt = opt
+
+    def forward(self, outputs, batch):
+        opt = self.opt
+        hm_loss = off_loss = poly_loss = depth_loss = order_loss = 0
+        for s in range(opt.num_stacks):
+            output = outputs[s]
+            depth_loss = depth_loss + self.crit_reg(
+                output["pseudo_depth"], batch["reg_mask"], batch["ind"],
+                batch["pseudo_depth"]) / opt.num_stacks
+            # _sigmoid + FocalLoss fused; output['hm'] becomes the activated map in place
+            hm_l, output["hm"] = sigmoid_focal_loss(output["hm"], batch["hm"])
+            hm_loss = hm_loss + hm_l / opt.num_stacks
+            r = self.crit_poly(output["poly"], batch["reg_mask"], batch["ind"], batch["poly"],
+                               freq_mask=batch.get("freq_mask"), peak=batch.get("peak"),
+                               hm=output["hm"])
+            if opt.poly_order:
+                poly_loss = poly_loss + r[0] / opt.num_stacks
+                order_loss = order_loss + r[1] / opt.num_stacks
+            else:
+                poly_loss = poly_loss + r / opt.num_stacks
+            if opt.reg_offset and opt.off_weight > 0:
+                off_loss = off_loss + self.crit_reg(output["reg"], batch["reg_mask"], batch["ind"],
+                                                    batch["reg"]) / opt.num_stacks
+        if opt.poly_order:
+            loss = opt.hm_weight * hm_loss + opt.off_weight * off_loss \
+                + opt.poly_weight * (poly_loss + order_loss) + opt.depth_weight * depth_loss
+            stats = {"loss": loss, "hm_l": hm_loss, "off_l": off_loss, "poly_l": poly_loss,
+                     "order_l": order_loss, "depth_l": depth_loss}
+        else:
+            loss = opt.hm_weight * hm_loss + opt.off_weight * off_loss \
+                + opt.poly_weight * poly_loss + opt.depth_weight * depth_loss
+            stats = {"loss": loss, "hm_l": hm_loss, "off_l": off_loss, "poly_l": poly_loss,
+                     "depth_l": depth_loss}
+        for k, v in stats.items():
+            if not torch.is_tensor(v):
+                stats[k] = batch["hm"].new_tensor(float(v))
+        return loss, stats
+
+
+class PolydetTrainer(BaseTrainer):
+    def __init__(self, opt, model, optimizer=None):
+        super(PolydetTrainer, self).__init__(opt, model, optimizer=optimizer)
+
+    def _get_losses(self, opt):
+        if opt.task != "polydet":
+            raise NotImplementedError
+        if opt.poly_order:
+            loss_states = ["loss", "hm_l", "off_l", "poly_l", "order_l", "depth_l"]
+        else:
+            loss_states = ["loss", "hm_l", "off_l", "poly_l", "depth_l"]
+        return loss_states, PolydetLoss(opt)
+
+    def debug(self, batch, output, iter_id):
+        raise NotImplementedError("the reference's debug() reads output['wh'], which polydet "
+                                  "never produces (trains/polydet.py:185-188)")
+
+    def save_result(self, output, batch, results):
+        reg = output["reg"] if self.opt.reg_offset else None
+        dets = polydet_decode(output["hm"], output["poly"], output["pseudo_depth"], reg=reg,
+                              cat_spec_poly=self.opt.cat_spec_poly, K=self.opt.K, rep=self.opt.rep)
+        dets = dets.detach().cpu().numpy().reshape(1, -1, dets.shape[2])
+        dets_out = polydet_post_process(
+            dets.copy(), batch["meta"]["c"].cpu().numpy(), batch["meta"]["s"].cpu().numpy(),
+            output["hm"].shape[2], output["hm"].shape[3], output["hm"].shape[1])
+        results[batch["meta"]["img_id"].cpu().numpy()[0]] = dets_out[0]

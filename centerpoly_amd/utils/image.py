@@ -1,0 +1,67 @@
+"""Affine helpers of the detector's host tail (reference: src/lib/utils/image.py:19-66).
+
+`cv2.getAffineTransform` is restated as the exact 3-point affine solve (numpy
+float64); `transform_preds` is vectorised over rows instead of a Python loop that
+recomputes the transform per call site.
+"""
+import numpy as np
+
+
+def get_3rd_point(a, b):
+    d = a - b
+    return b + np.array([-d[1], d[0]], dtype=np.float32)
+
+
+def get_dir(src_point, rot_rad):
+    sn, cs = np.sin(rot_rad), np.cos(rot_rad)
+    return [src_point[0] * cs - src_point[1] * sn, src_point[0] * sn + src_point[1] * cs]
+
+
+def _solve_affine(src, dst):
+    A = np.zeros((6, 6), dtype=np.float64)
+    b = np.zeros(6, dtype=np.float64)
+    for k in range(3):
+        A[2 * k, 0:3] = (src[k, 0], src[k, 1], 1.0)
+        A[2 * k + 1, 3:6] = (src[k, 0], src[k, 1], 1.0)
+        b[2 * k:2 * k + 2] = dst[k]
+    return np.linalg.solve(A, b).reshape(2, 3)
+
+
+def get_affine_transform(center, scale, rot, output_size,
+                         shift=np.array([0, 0], dtype=np.float32), inv=0):
+    if not isinstance(scale, np.ndarray) and not isinstance(scale, list):
+        scale = np.array([scale, scale], dtype=np.float32)
+    scale_tmp = scale
+    src_w = scale_tmp[0]
+    dst_w, dst_h = output_size[0], output_size[1]
+    src_dir = get_dir([0, src_w * -0.5], np.pi * rot / 180)
+    dst_dir = np.array([0, dst_w * -0.5], np.float32)
+    src = np.zeros((3, 2), dtype=np.float32)
+    dst = np.zeros((3, 2), dtype=np.float32)
+    src[0, :] = center + scale_tmp * shift
+    src[1, :] = center + src_dir + scale_tmp * shift
+    dst[0, :] = [dst_w * 0.5, dst_h * 0.5]
+    dst[1, :] = np.array([dst_w * 0.5, dst_h * 0.5], np.float32) + dst_dir
+    src[2:, :] = get_3rd_point(src[0, :], src[1, :])
+    dst[2:, :] = get_3rd_point(dst[0, :], dst[1, :])
+    if inv:
+        return _solve_affine(np.float32(dst), np.float32(src))
+    return _solve_affine(np.float32(src), np.float32(dst))
+
+
+def affine_transform(pt, t):
+    new_pt = np.array([pt[0], pt[1], 1.0], dtype=np.float32).T
+    return np.dot(t, new_pt)[:2]
+
+
+def apply_affine(coords, trans):
+    """All rows at once: [n,2] fp32 points through a 2x3 float64 matrix."""
+    pts = np.concatenate([coords[:, 0:2].astype(np.float32),
+                          np.ones((coords.shape[0], 1), np.float32)], axis=1)
+    return pts @ trans.T
+
+
+def transform_preds(coords, center, scale, output_size):
+    target = np.zeros(coords.shape)
+    target[:, 0:2] = apply_affine(coords, get_affine_transform(center, scale, 0, output_size, inv=1))
+    return target

@@ -1,0 +1,183 @@
+/*
+ * centerpoly_hip.h -- C ABI of libcenterpoly_hip.so (MI355X / gfx950).
+ *
+ * The drop-in boundary of the CenterPoly v2 `polydet` hot path.  Every entry
+ * point takes raw DEVICE pointers, explicit sizes and a hipStream_t (passed as
+ * void*); the library never allocates, frees or keeps a pointer after the call
+ * returns, holds no global mutable state, is re-entrant and asynchronous on the
+ * supplied stream.  Return value: CP_OK (0) or a negative CP_E* code; no C++
+ * exception crosses this boundary.
+ *
+ * Which reference interface each entry point replaces (paths are relative to
+ * the reference tree, /root/reference):
+ *
+ *   cp_dcn_v2_forward / cp_dcn_v2_backward
+ *       the native extension behind `from .DCNv2.dcn_v2 import DCN`
+ *       (src/lib/models/networks/pose_dla_dcn.py:16, call site :354;
+ *       src/lib/models/networks/resnet_dcn.py:18,221).  Upstream
+ *       CharlesShang/DCNv2 (absent from the tree) exposes
+ *       dcn_v2_forward(input, weight, bias, offset, mask, kh,kw, sh,sw, ph,pw,
+ *       dh,dw, dg) and dcn_v2_backward(..., grad_output) -> (grad_input,
+ *       grad_offset, grad_mask, grad_weight, grad_bias).
+ *   cp_polydet_decode
+ *       _nms + _topk + polydet_decode, src/lib/models/decode.py:13-19, 117-133,
+ *       512-670, and the gather helpers src/lib/models/utils.py:12-26.
+ *   cp_sigmoid_focal_forward / cp_sigmoid_focal_backward
+ *       _sigmoid (src/lib/models/utils.py:8-10) + _neg_loss / FocalLoss
+ *       (src/lib/models/losses.py:146-171, 792-799) as used at
+ *       src/lib/trains/polydet.py:46,84.
+ *   cp_gather_l1_forward / cp_gather_l1_backward
+ *       _transpose_and_gather_feat + RegL1Loss (src/lib/models/losses.py:817-830)
+ *       and the regression part of PolyLoss (src/lib/models/losses.py:910-949).
+ *   cp_poly_iou_order_forward / cp_poly_iou_order_backward
+ *       the per-object loop of PolyLoss (src/lib/models/losses.py:868-909) with
+ *       WeilPolygonClipper (:373-628) and area (:25-41).
+ *
+ * All tensors are dense fp32 NCHW unless stated.  "B" is the per-device batch.
+ */
+#ifndef CENTERPOLY_HIP_H
+#define CENTERPOLY_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CP_ABI_VERSION 1
+
+enum {
+  CP_OK = 0,
+  CP_EINVAL = -1,       /* null pointer, non-positive size, inconsistent arguments */
+  CP_EUNSUPPORTED = -2, /* valid but not implemented shape/option */
+  CP_EWORKSPACE = -3,   /* workspace smaller than cp_*_workspace_bytes() */
+  CP_EHIP = -4          /* a HIP runtime call or kernel launch failed */
+};
+
+/* representation of the polygon head (src/lib/opts.py `--rep`) */
+enum { CP_REP_CARTESIAN = 0, CP_REP_POLAR = 1, CP_REP_POLAR_FIXED = 2 };
+
+/* regression flavour for cp_gather_l1_* */
+enum {
+  CP_L1_PLAIN = 0,       /* RegL1Loss / PolyLoss cartesian: sum |p*m - t*m|            */
+  CP_L1_POLAR = 1,       /* PolyLoss polar: L1 on even slots + sum(1-cos) on odd slots */
+  CP_L1_POLAR_FIXED = 2, /* PolyLoss polar_fixed: L1 on even (radius) slots only       */
+  CP_L1_RELU20 = 3       /* PolyLoss 'relu': |p-t| kept only where >= 20               */
+};
+
+int cp_abi_version(void);
+const char* cp_strerror(int code);
+/* Name of the HIP device architecture the library was built for ("gfx950"). */
+const char* cp_build_arch(void);
+
+/* ------------------------------------------------------------------ DCNv2 --
+ * Modulated deformable convolution, kernel kh x kw, one deformable group.
+ *   x        [B, Cin, H, W]
+ *   offset   per-tap (dy, dx) interleaved: channel 2k = dy_k, 2k+1 = dx_k,
+ *            k = ky*kw + kx; element (b, ch, ho, wo) at
+ *            offset[b*offset_bstride + ch*Ho*Wo + ho*Wo + wo]
+ *   mask     [.., kh*kw, Ho, Wo], batch stride mask_bstride; if mask_is_logit != 0
+ *            the kernel applies sigmoid itself (lets the caller pass the raw
+ *            27-channel conv_offset_mask output: offset = om, mask = om + 18*Ho*Wo,
+ *            both batch strides 27*Ho*Wo, without chunk/cat/sigmoid passes)
+ *   weight   [Cout, Cin, kh, kw], bias [Cout] or NULL
+ *   out      [B, Cout, Ho, Wo]
+ * Optional fused epilogue (inference): out = act(acc * ep_scale[co] + ep_shift[co])
+ * with ep_scale/ep_shift NULL meaning scale 1 / shift = bias; relu != 0 clamps at 0.
+ * When ep_scale/ep_shift are given, bias must already be folded into ep_shift.
+ */
+typedef struct cp_dcn_shape {
+  int32_t B, Cin, H, W, Cout;
+  int32_t kh, kw, stride, pad, dil;
+  int32_t deformable_groups; /* only 1 is implemented */
+} cp_dcn_shape;
+
+int cp_dcn_v2_forward(const cp_dcn_shape* s, const float* x, const float* offset,
+                      int64_t offset_bstride, const float* mask, int64_t mask_bstride,
+                      int32_t mask_is_logit, const float* weight, const float* bias,
+                      const float* ep_scale, const float* ep_shift, int32_t relu, float* out,
+                      void* stream);
+
+/* Backward.  grad_* outputs may be NULL to skip that gradient.  grad_x,
+ * grad_weight and grad_bias are ACCUMULATED INTO (caller zero-fills);
+ * grad_offset / grad_mask are overwritten.  mask is the post-sigmoid mask
+ * (mask_is_logit == 0) or the logits (then grad_mask is w.r.t. the logits). */
+size_t cp_dcn_v2_backward_workspace_bytes(const cp_dcn_shape* s);
+int cp_dcn_v2_backward(const cp_dcn_shape* s, const float* x, const float* offset,
+                       int64_t offset_bstride, const float* mask, int64_t mask_bstride,
+                       int32_t mask_is_logit, const float* weight, const float* grad_out,
+                       float* grad_x, float* grad_offset, int64_t grad_offset_bstride,
+                       float* grad_mask, int64_t grad_mask_bstride, float* grad_weight,
+                       float* grad_bias, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ----------------------------------------------------------------- decode --
+ * heat [B,C,H,W] (already activated), polys [B,2N,H,W], depth [B,1,H,W],
+ * reg [B,2,H,W] or NULL (then +0.5).  K <= 256.
+ * Outputs: dets [B,K,2N+7] = [x1,y1,x2,y2,score,cls,poly(2N),depth],
+ * inds [B,K] int64 (flat y*W+x), clses [B,K] int32 (both may be NULL).
+ * Selection order: score descending, ties by (class, flat index) ascending --
+ * the order a stable sort of the reference's two-level top-k yields.
+ */
+size_t cp_polydet_decode_workspace_bytes(int32_t B, int32_t C, int32_t H, int32_t W, int32_t K);
+int cp_polydet_decode(const float* heat, const float* polys, const float* depth, const float* reg,
+                      int32_t B, int32_t C, int32_t H, int32_t W, int32_t N2, int32_t K,
+                      int32_t rep, float* dets, int64_t* inds, int32_t* clses, void* workspace,
+                      size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------- focal loss --
+ * forward: hm[n] <- clamp(sigmoid(hm[n]), 1e-4, 1-1e-4) IN PLACE (the reference
+ * mutates output['hm'] the same way) and loss_out[0] <- CornerNet focal loss;
+ * stats_out[0..2] <- {sum pos term, sum neg term, num_pos} (device floats).
+ * backward: grad_logits[n] <- grad_loss[0] * dLoss/dlogit from the ACTIVATED hm.
+ */
+size_t cp_sigmoid_focal_workspace_bytes(int64_t n);
+int cp_sigmoid_focal_forward(float* hm_inout, const float* gt, int64_t n, float* loss_out,
+                             float* stats_out, void* workspace, size_t workspace_bytes,
+                             void* stream);
+int cp_sigmoid_focal_backward(const float* hm_act, const float* gt, int64_t n,
+                              const float* stats, const float* grad_loss, float* grad_logits,
+                              void* stream);
+
+/* ----------------------------------------------------- gathered L1 losses --
+ * feat [B,D,H,W]; ind [B,M] int64; mask [B,M] uint8; target [B,M,D].
+ * pred[b,m,d] = feat[b,d,ind[b,m]] (no NHWC copy).
+ * loss_out[0] = S / (sum(mask)*D + eps), S by `mode` (CP_L1_*).
+ * pred_add [B,M,D] or NULL: constant added to pred before the loss (the order
+ * term's in-place `angles += 2*3.14`, src/lib/models/losses.py:892-899).
+ * backward scatter-ADDS grad_loss[0] * dS/dfeat / denom into grad_feat (caller zero-fills).
+ */
+int cp_gather_l1_forward(const float* feat, const int64_t* ind, const uint8_t* mask,
+                         const float* target, const float* pred_add, int32_t B, int32_t D,
+                         int32_t H, int32_t W, int32_t M, int32_t mode, float eps,
+                         float* loss_out, void* stream);
+int cp_gather_l1_backward(const float* feat, const int64_t* ind, const uint8_t* mask,
+                          const float* target, const float* pred_add, int32_t B, int32_t D,
+                          int32_t H, int32_t W, int32_t M, int32_t mode, float eps,
+                          const float* grad_loss, float* grad_feat, void* stream);
+
+/* ----------------------------------- polygon IoU (Weiler-Atherton) + order --
+ * feat = polygon head [B,2N,H,W]; per masked object the literal reference
+ * computation (every point read as (r, theta), doubled first shoelace term,
+ * early-terminating traversal).  flags: bit0 = IoU term, bit1 = order term.
+ *   iou_loss_out[0]   = 1 - sum(iou) / (sum(mask) + 1e-6)          (bit0)
+ *   order_loss_out[0] = sum(hinge) / (10*sum(mask) + 1e-4)         (bit1)
+ *   pred_add_out [B,M,2N] (bit1): the +2*3.14 edits, to feed cp_gather_l1_*.
+ * backward scatter-ADDS into grad_feat (caller zero-fills).
+ */
+size_t cp_poly_iou_order_workspace_bytes(int32_t B, int32_t M, int32_t N);
+int cp_poly_iou_order_forward(const float* feat, const int64_t* ind, const uint8_t* mask,
+                              const float* target, int32_t B, int32_t N, int32_t H, int32_t W,
+                              int32_t M, int32_t flags, float* iou_loss_out,
+                              float* order_loss_out, float* pred_add_out, void* workspace,
+                              size_t workspace_bytes, void* stream);
+int cp_poly_iou_order_backward(const float* feat, const int64_t* ind, const uint8_t* mask,
+                               const float* target, int32_t B, int32_t N, int32_t H, int32_t W,
+                               int32_t M, int32_t flags, const float* grad_iou_loss,
+                               const float* grad_order_loss, float* grad_feat, void* workspace,
+                               size_t workspace_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CENTERPOLY_HIP_H */

@@ -1,0 +1,342 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle and the
+reference-generated golden vectors, on identical seeded inputs.
+
+Tolerances (north_star): top-k / NMS indices bit-exact; fp32 heat maps, vertex
+offsets and losses within 1e-3 relative (most checks are far tighter).
+"""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+import cases
+from centerpoly_amd import _C, synth
+from oracle import dcn as odcn
+from oracle import decode as odec
+from oracle import losses as olos
+
+pytestmark = pytest.mark.gpu
+T = torch.from_numpy
+DEV = "cuda"
+
+
+def g(a):
+    return (T(a) if isinstance(a, np.ndarray) else a).to(DEV)
+
+
+# ----------------------------------------------------------------- decode ---
+
+@pytest.mark.parametrize("case", cases.DECODE_CASES, ids=lambda c: c[0])
+def test_decode_vs_oracle_and_golden(case, golden):
+    from centerpoly_amd.models.decode import polydet_decode
+    name, B, C, h, w, N, K, rep = case
+    heat, polys, depth, reg = (T(a) for a in cases.decode_inputs_np(*case))
+    for use_reg, key in ((True, "dets"), (False, "dets_noreg")):
+        ref, rinds, rcls = odec.polydet_decode(heat, polys, depth, reg if use_reg else None, K=K, rep=rep)
+        dets, inds, clses = polydet_decode(g(heat), g(polys), g(depth), reg=g(reg) if use_reg else None,
+                                           K=K, rep=rep, return_inds=True)
+        assert torch.equal(inds.cpu(), rinds), "top-k indices must be bit-exact"
+        assert torch.equal(clses.cpu(), rcls)
+        d = dets.cpu()
+        assert torch.equal(d[..., 4], ref[..., 4])            # scores bit-exact
+        if rep == "cartesian":
+            assert torch.equal(d, ref)                         # whole record bit-exact
+        else:
+            np.testing.assert_allclose(d.numpy(), ref.numpy(), rtol=1e-6, atol=1e-5)
+        gold = golden("decode_" + name)
+        assert np.array_equal(inds.cpu().numpy(), gold["inds"])
+        np.testing.assert_allclose(d.numpy(), gold[key], rtol=1e-6, atol=1e-5)
+
+
+def _decode_both(heat, N=4, K=16, rep="cartesian"):
+    from centerpoly_amd.models.decode import polydet_decode
+    B, C, h, w = heat.shape
+    polys = T(synth.normal("tie/poly", (B, 2 * N, h, w)))
+    depth = T(synth.uniform("tie/depth", (B, 1, h, w)))
+    reg = T(synth.uniform("tie/reg", (B, 2, h, w)))
+    ref, rinds, rcls = odec.polydet_decode(heat, polys, depth, reg, K=K, rep=rep)
+    dets, inds, clses = polydet_decode(g(heat), g(polys), g(depth), reg=g(reg), K=K, rep=rep,
+                                       return_inds=True)
+    return ref, rinds, rcls, dets.cpu(), inds.cpu(), clses.cpu()
+
+
+@pytest.mark.parametrize("kind", ["constant", "sparse", "plateaus", "zeros", "ragged"])
+def test_decode_ties_and_edge_inputs(kind):
+    if kind == "constant":            # every pixel is a 3x3 maximum: all tie
+        heat = torch.full((2, 3, 40, 52), 0.25)
+    elif kind == "zeros":
+        heat = torch.zeros((1, 8, 64, 64))
+    elif kind == "sparse":            # fewer positives than K -> zeros fill in index order
+        heat = torch.zeros((2, 8, 64, 96))
+        idx = synth.integers("tie/sparse", (2, 9), 0, 8 * 64 * 96)
+        for b in range(2):
+            heat[b].view(-1)[T(idx[b])] = T(synth.uniform("tie/v%d" % b, (9,), 0.1, 0.9))
+    elif kind == "plateaus":          # quantised field: many equal maxima
+        heat = torch.round(T(synth.smooth_field("tie/pl", (1, 4, 48, 80))) * 2) / 8 + 0.5
+    else:                             # ragged: C*H*W not a multiple of the 4096 tile, odd W
+        heat = torch.sigmoid(T(synth.heat_logits("tie/rag", 3, 5, 37, 53)))
+    ref, rinds, rcls, dets, inds, clses = _decode_both(heat, K=100 if kind != "ragged" else 77)
+    assert torch.equal(inds, rinds) and torch.equal(clses, rcls)
+    assert torch.equal(dets, ref)
+
+
+def test_decode_full_size_config2():
+    """BASELINE config 2 shape: 8 x 256 x 512 heat, K=128, N=16."""
+    heat = torch.sigmoid(T(synth.heat_logits("full/hm", 1, 8, 256, 512)))
+    ref, rinds, rcls, dets, inds, clses = _decode_both(heat, N=16, K=128)
+    assert torch.equal(inds, rinds) and torch.equal(clses, rcls) and torch.equal(dets, ref)
+    # size-independent properties: sorted scores, indices in range and unique per (cls, ind)
+    s = dets[0, :, 4]
+    assert bool((s[:-1] >= s[1:]).all())
+    keys = clses[0].long() * 256 * 512 + inds[0]
+    assert keys.unique().numel() == 128
+
+
+def test_decode_rejects_bad_arguments():
+    from centerpoly_amd.models.decode import polydet_decode
+    heat = torch.rand(1, 2, 8, 8, device=DEV)
+    with pytest.raises(_C.NativeError):
+        polydet_decode(heat, torch.zeros(1, 4, 8, 8, device=DEV), torch.zeros(1, 1, 8, 8, device=DEV),
+                       K=300)           # K > 256 unsupported
+    with pytest.raises(_C.NativeError):
+        polydet_decode(heat, torch.zeros(1, 4, 8, 8, device=DEV), torch.zeros(1, 1, 8, 8, device=DEV),
+                       K=129)           # K > C*H*W
+
+
+# ------------------------------------------------------------------ focal ---
+
+def test_sigmoid_focal_vs_oracle_and_golden(golden):
+    from centerpoly_amd.models.losses import sigmoid_focal_loss
+    batch, out = cases.loss_batch("base", 2, 32, 48, 16, "cartesian")
+    gold = golden("loss_focal")
+    x = g(out["hm"]).requires_grad_(True)
+    loss, act = sigmoid_focal_loss(x.clone(), g(batch["hm"]))
+    loss.backward()
+    np.testing.assert_allclose(act.detach().cpu().numpy(), gold["act"], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(loss.item(), gold["loss"], rtol=1e-5)
+    scale = np.abs(gold["grad"]).max()
+    np.testing.assert_allclose(x.grad.cpu().numpy(), gold["grad"], rtol=1e-3, atol=1e-6 * scale)
+    # num_pos == 0 branch
+    g0 = golden("loss_focal_nopos")
+    x0 = g(out["hm"]).requires_grad_(True)
+    l0, _ = sigmoid_focal_loss(x0.clone(), torch.zeros_like(x0))
+    l0.backward()
+    np.testing.assert_allclose(l0.item(), g0["loss"], rtol=1e-5)
+    np.testing.assert_allclose(x0.grad.cpu().numpy(), g0["grad"], rtol=1e-3,
+                               atol=1e-6 * np.abs(g0["grad"]).max())
+
+
+def test_sigmoid_focal_full_size_and_extremes():
+    from centerpoly_amd.models.losses import sigmoid_focal_loss
+    B, C, h, w = 2, 8, 256, 512
+    logits = synth.heat_logits("focal/full", B, C, h, w)
+    logits.reshape(-1)[:64] = np.linspace(-30, 30, 64)          # saturates both clamp ends
+    gt = synth.train_batch(B, h, w, with_input=False, stream="focal/gt")["hm"]
+    x = T(logits).requires_grad_(True)
+    ref = olos.neg_loss(olos.sigmoid_clamp(x), T(gt))
+    ref.backward()
+    xd = g(logits).requires_grad_(True)
+    loss, act = sigmoid_focal_loss(xd.clone(), g(gt))
+    loss.backward()
+    np.testing.assert_allclose(loss.item(), ref.item(), rtol=1e-4)
+    gs = x.grad.abs().max().item()
+    np.testing.assert_allclose(xd.grad.cpu().numpy(), x.grad.numpy(), rtol=1e-3, atol=1e-5 * gs)
+    a = act.detach()
+    assert float(a.min()) >= float(np.float32(1e-4)) and float(a.max()) <= float(np.float32(1 - 1e-4))
+
+
+# ------------------------------------------------------------ gathered L1 ---
+
+@pytest.mark.parametrize("key", ["reg", "pseudo_depth"])
+def test_regl1_vs_golden(key, golden):
+    from centerpoly_amd.models.losses import RegL1Loss
+    batch, out = cases.loss_batch("base", 2, 32, 48, 16, "cartesian")
+    gold = golden("loss_regl1_" + key)
+    o = g(out[key]).requires_grad_(True)
+    l = RegL1Loss()(o, g(batch["reg_mask"]), g(batch["ind"]), g(batch[key]))
+    l.backward()
+    np.testing.assert_allclose(l.item(), gold["loss"], rtol=1e-5)
+    np.testing.assert_allclose(o.grad.cpu().numpy(), gold["grad"], rtol=1e-5, atol=1e-9)
+
+
+class _Opt:
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+
+L1_ONLY = [c for c in cases.POLY_CASES if c[6] == "l1" and not c[7]]
+
+
+@pytest.mark.parametrize("case", L1_ONLY, ids=lambda c: c[0])
+def test_polyloss_l1_variants_vs_golden(case, golden):
+    from centerpoly_amd.models.losses import PolyLoss
+    name, B, h, w, N, rep, pl, order = case
+    gold = golden("loss_poly_" + name)
+    batch, out = cases.loss_batch(name, B, h, w, N, rep)
+    o = g(out["poly"]).requires_grad_(True)
+    l = PolyLoss(_Opt(poly_loss=pl, rep=rep, poly_order=order))(
+        o, g(batch["reg_mask"]), g(batch["ind"]), g(batch["poly"]))
+    l.backward()
+    np.testing.assert_allclose(l.item(), gold["loss"], rtol=1e-5)
+    idx = g(batch["ind"])
+    rows = torch.gather(o.grad.view(B, 2 * N, -1), 2, idx.unsqueeze(1).expand(B, 2 * N, idx.shape[1]))
+    np.testing.assert_allclose(rows.cpu().numpy(), gold["grad_rows"], rtol=1e-3,
+                               atol=1e-6 * np.abs(gold["grad_rows"]).max())
+    np.testing.assert_allclose(o.grad.abs().double().sum().item(), gold["grad_abs_sum"], rtol=1e-4)
+
+
+def test_gather_l1_duplicate_centres_accumulate():
+    from centerpoly_amd.models.losses import RegL1Loss
+    feat = g(synth.normal("dup/f", (1, 2, 8, 8))).requires_grad_(True)
+    ind = torch.tensor([[5, 5, 9]], device=DEV)
+    mask = torch.tensor([[1, 1, 1]], dtype=torch.uint8, device=DEV)
+    tgt = g(synth.normal("dup/t", (1, 3, 2)))
+    l = RegL1Loss()(feat, mask, ind, tgt)
+    l.backward()
+    fc = feat.detach().cpu().requires_grad_(True)
+    lr = olos.reg_l1_loss(fc, mask.cpu(), ind.cpu(), tgt.cpu())
+    lr.backward()
+    np.testing.assert_allclose(l.item(), lr.item(), rtol=1e-6)
+    np.testing.assert_allclose(feat.grad.cpu().numpy(), fc.grad.numpy(), rtol=1e-6, atol=1e-9)
+
+
+# -------------------------------------------------------------------- DCN ---
+
+DCN_SHAPES = [
+    # B, Cin, Cout, H, W
+    (1, 64, 64, 32, 64),
+    (2, 128, 64, 24, 40),
+    (1, 256, 128, 16, 32),
+    (1, 512, 256, 8, 16),
+    (1, 256, 256, 12, 20),
+    (2, 24, 40, 13, 19),        # ragged: channels not multiples of the tile, odd extent
+    (1, 8, 300, 9, 7),          # Cout > 256 -> two N tiles
+]
+
+
+def _dcn_inputs(tag, B, Cin, Cout, H, W, offset_scale=2.0):
+    x = synth.normal("dcn/%s/x" % tag, (B, Cin, H, W))
+    om = synth.normal("dcn/%s/om" % tag, (B, 27, H, W), 0.0, offset_scale)
+    w = synth.normal("dcn/%s/w" % tag, (Cout, Cin, 3, 3), 0.0, 1.0 / np.sqrt(Cin * 9))
+    b = synth.normal("dcn/%s/b" % tag, (Cout,), 0.0, 0.1)
+    return x, om, w, b
+
+
+def _dcn_ref(x, om, w, b):
+    o1, o2, m = torch.chunk(T(om), 3, dim=1)
+    return odcn.dcn_v2_forward(T(x), torch.cat((o1, o2), 1), torch.sigmoid(m), T(w), T(b))
+
+
+@pytest.mark.parametrize("shape", DCN_SHAPES, ids=lambda s: "x".join(map(str, s)))
+def test_dcn_forward_vs_oracle(shape):
+    from centerpoly_amd.models.networks.DCNv2.dcn_v2 import dcn_v2_forward_raw
+    B, Cin, Cout, H, W = shape
+    x, om, w, b = _dcn_inputs("%dx%d" % (Cin, Cout), *shape)
+    ref = _dcn_ref(x, om, w, b)
+    out = dcn_v2_forward_raw(g(x), g(om), g(w), g(b)).cpu()
+    scale = ref.abs().max().item()
+    np.testing.assert_allclose(out.numpy(), ref.numpy(), rtol=1e-3, atol=2e-5 * scale)
+
+
+def test_dcn_large_offsets_and_borders():
+    """Offsets that throw samples far outside the image (zero contribution) and exactly
+    onto integer / border positions."""
+    from centerpoly_amd.models.networks.DCNv2.dcn_v2 import dcn_v2_forward_raw
+    B, Cin, Cout, H, W = 1, 16, 32, 10, 12
+    x, om, w, b = _dcn_inputs("border", B, Cin, Cout, H, W, offset_scale=9.0)
+    om[:, :18, :2] = np.round(om[:, :18, :2])                  # integer offsets
+    om[:, :18, 2:4] = -1.0                                       # lands on -1 / H-1 edges
+    ref = _dcn_ref(x, om, w, b)
+    out = dcn_v2_forward_raw(g(x), g(om), g(w), g(b)).cpu()
+    np.testing.assert_allclose(out.numpy(), ref.numpy(), rtol=1e-3, atol=2e-5 * ref.abs().max().item())
+
+
+def test_dcn_zero_offset_known_answer():
+    """Upstream zero-initialises conv_offset_mask => DCN(x) == 0.5*conv2d(x, W, pad=1) + b."""
+    from centerpoly_amd.models.networks.DCNv2.dcn_v2 import DCN
+    d = DCN(32, 48, kernel_size=(3, 3), stride=1, padding=1, dilation=1, deformable_groups=1).to(DEV)
+    with torch.no_grad():
+        d.bias.copy_(g(synth.normal("dcn/kat/b", (48,))))
+        x = g(synth.normal("dcn/kat/x", (2, 32, 20, 28)))
+        out = d(x)
+        ref = 0.5 * torch.nn.functional.conv2d(x.cpu(), d.weight.cpu(), None, padding=1) \
+            + d.bias.cpu().view(1, -1, 1, 1)
+    np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), rtol=1e-4, atol=1e-5)
+
+
+def test_dcn_fused_bn_relu_epilogue():
+    from centerpoly_amd.models.networks.pose_dla_dcn import DeformConv
+    m = DeformConv(32, 64).to(DEV)
+    sd = {k: T(v) for k, v in cases.fill_weights({k: tuple(v.shape) for k, v in m.state_dict().items()}).items()}
+    m.load_state_dict(sd)
+    x = g(synth.normal("dcn/fused/x", (1, 32, 16, 24)))
+    m.eval()
+    with torch.no_grad():
+        fused = m(x)                                  # one kernel
+    with torch.enable_grad():
+        plain = m.actf(m.conv(x)).detach()            # DCN, then torch BN + ReLU
+    np.testing.assert_allclose(fused.cpu().numpy(), plain.cpu().numpy(), rtol=1e-4, atol=1e-5)
+
+
+# ------------------------------------------------------------------- nets ---
+
+def _load_by_name(model, gold):
+    shapes = {k: tuple(v) for k, v in json.loads(str(gold["shapes"])).items()}
+    model.load_state_dict({k: T(v) for k, v in cases.fill_weights(shapes).items()})
+    return model.to(DEV).eval()
+
+
+def test_dla34_forward_vs_reference_golden(golden):
+    """Reference DLASeg wiring (with the oracle's DCN in the plugin slot) vs the HIP path."""
+    from centerpoly_amd.models.model import create_model
+    gold = golden("net_dla34")
+    m = _load_by_name(create_model("dla_34", dict(cases.HEADS), 256), gold)
+    with torch.no_grad():
+        out = m(g(cases.net_input("dla")))[0]
+    for h in dict(cases.HEADS):
+        ref = gold["s0_" + h]
+        np.testing.assert_allclose(out[h].cpu().numpy(), ref, rtol=1e-3, atol=1e-4 * np.abs(ref).max())
+
+
+@pytest.mark.parametrize("arch,ns", [("smallhourglass", 1), ("hourglass", 2)])
+def test_hourglass_forward_vs_reference_golden(arch, ns, golden):
+    from centerpoly_amd.models.model import create_model
+    gold = golden("net_hourglass%d" % ns)
+    m = _load_by_name(create_model(arch, dict(cases.HEADS), 64), gold)
+    with torch.no_grad():
+        outs = m(g(cases.net_input("hourglass")))
+    for s in range(ns):
+        for h in dict(cases.HEADS):
+            ref = gold["s%d_%s" % (s, h)]
+            np.testing.assert_allclose(outs[s][h].cpu().numpy(), ref, rtol=2e-3,
+                                       atol=2e-4 * np.abs(ref).max())
+
+
+def test_detector_run_config1_plumbing():
+    """BASELINE config 1 (Hourglass-small, one synthetic 512x512 image, 16-vertex cartesian)
+    through PolydetDetector.run, decode checked against the oracle on the same head outputs."""
+    from centerpoly_amd.detectors.detector_factory import detector_factory
+    from centerpoly_amd.opts import opts
+    from oracle import post as opost
+    opt = opts().init(["polydet", "--arch", "smallhourglass", "--input_h", "512", "--input_w", "512"])
+    torch.manual_seed(317)
+    det = detector_factory["polydet"](opt)
+    img = (synth.uniform("cfg1/img", (512, 512, 3)) * 255).astype(np.uint8)
+    ret = det.run(img)
+    assert set(ret) == {"results", "tot", "load", "pre", "net", "dec", "post", "merge"}
+    res = ret["results"]
+    assert sorted(res) == list(range(1, 9))
+    assert sum(len(v) for v in res.values()) == opt.K
+    assert all(v.shape[1] == 2 * 16 + 6 for v in res.values())
+    # oracle on the same head outputs
+    images, meta = det.pre_process(img, 1.0)
+    with torch.no_grad():
+        out = det.model(images.to(DEV))[-1]
+        hm = out["hm"].sigmoid().cpu()
+    dref, _, _ = odec.polydet_decode(hm, out["poly"].cpu(), out["pseudo_depth"].cpu(), out["reg"].cpu(),
+                                     K=opt.K, rep="cartesian")
+    ref = opost.merge_outputs([opost.detector_post_process(dref.numpy(), meta, 1.0, 8)], 8, opt.K)
+    for j in range(1, 9):
+        assert res[j].shape == ref[j].shape
+        np.testing.assert_allclose(res[j], ref[j], rtol=1e-5, atol=1e-3)
