@@ -7,15 +7,22 @@
 // Tiling: one workgroup (4 waves) = 64 consecutive output pixels of one image x
 // BN output channels.  K = Cin*kh*kw is walked in chunks of KC input channels:
 //   1. every lane owns one pixel and keeps that pixel's kh*kw sampling recipes
-//      (4 corner weights, pre-multiplied by mask and validity, + 4 clamped
-//      indices) in registers for the whole K loop;
+//      (4 corner weights, pre-multiplied by mask and validity, + the clamped
+//      top-left index and 2 step bits) in registers for the whole K loop;
 //   2. wave w samples channels {c0 + w*KC/4 ...} of the chunk: lanes = adjacent
 //      pixels, so the 4 corner reads of a (channel, tap) are near-contiguous;
 //   3. the weight chunk [BN][KC*9] is staged to LDS with coalesced row reads;
 //   4. v_mfma_f32_16x16x4_f32 over the chunk (exact fp32 fma chain).
+// Gathers are issued 36 at a time (all taps x corners of a channel) before any use,
+// so a wave keeps a full batch of L1/L2 requests in flight.  Layers whose grid
+// would not fill the 256 CUs take narrower N tiles and a split over K whose
+// partial sums meet in a small reduce+epilogue kernel (workspace supplied by caller).
 // LDS rows are padded to an odd dword count so both the lane=pixel writes and the
 // lane=(row, k) fragment reads are bank-conflict free.
 #include "cp_common.h"
+#ifdef CP_ABLATE
+#include <stdlib.h>
+#endif
 
 namespace {
 
@@ -31,14 +38,26 @@ struct DcnFwdArgs {
   const float* ep_scale;
   const float* ep_shift;
   float* out;
+  float* partial;            // [S][B][Cout][Ho*Wo] when splitk > 1
   long long offset_bstride, mask_bstride;
   int B, Cin, H, W, Cout, Ho, Wo;
   int stride, pad, dil;
   int mask_is_logit, relu;
+  int splitk, c_per_split;   // K split: this many input channels per z-slice
+#ifdef CP_ABLATE
+  int ablate;                // timing-only build: bit0 no gathers, bit1 no colT writes,
+                             // bit2 no weight staging, bit3 no MFMA (results are wrong)
+#endif
 };
 
-template <int BN, int KC>
-__global__ __launch_bounds__(256) void dcn_fwd_kernel(DcnFwdArgs a) {
+#ifdef CP_ABLATE
+#define CP_ABL(bit) (a.ablate & (bit))
+#else
+#define CP_ABL(bit) 0
+#endif
+
+template <int BN, int KC, int WPS>
+__global__ __launch_bounds__(256, WPS) void dcn_fwd_kernel(DcnFwdArgs a) {
   constexpr int KK = KC * TAPS;          // k extent of one chunk
   constexpr int LD = KK + 1;             // odd row stride (dwords)
   constexpr int NT = BN / 32;            // 16-wide n tiles per wave
@@ -51,7 +70,7 @@ __global__ __launch_bounds__(256) void dcn_fwd_kernel(DcnFwdArgs a) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wid = tid >> 6;
-  const int b = blockIdx.z;
+  const int b = blockIdx.z % a.B;
   const int n0 = blockIdx.y * BN;
   const int HWo = a.Ho * a.Wo;
   const int HW = a.H * a.W;
@@ -59,25 +78,30 @@ __global__ __launch_bounds__(256) void dcn_fwd_kernel(DcnFwdArgs a) {
   const bool p_ok = p < HWo;
 
   // ---- per-pixel sampling recipes, kept in registers ----
+  // cw[t][0..3]: corner weights x mask x validity; cbase[t]: clamped top-left index;
+  // bit 2t of cstep: right neighbour is +1 (else same column), bit 2t+1: lower is +W.
   float cw[TAPS][4];
-  int ci[TAPS][4];
+  int cbase[TAPS];
+  unsigned cstep = 0;
   {
     const int ho = p_ok ? p / a.Wo : 0;
     const int wo = p_ok ? p - ho * a.Wo : 0;
     const float* off = a.offset + (long long)b * a.offset_bstride;
     const float* msk = a.mask + (long long)b * a.mask_bstride;
+    float oy[TAPS], ox[TAPS], mk[TAPS];
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t) {
+      oy[t] = p_ok ? off[(long long)(2 * t) * HWo + p] : 0.f;
+      ox[t] = p_ok ? off[(long long)(2 * t + 1) * HWo + p] : 0.f;
+      mk[t] = p_ok ? msk[(long long)t * HWo + p] : 0.f;
+    }
 #pragma unroll
     for (int t = 0; t < TAPS; ++t) {
       const int ky = t / 3, kx = t - ky * 3;
-      float oy = 0.f, ox = 0.f, m = 0.f;
-      if (p_ok) {
-        oy = off[(long long)(2 * t) * HWo + p];
-        ox = off[(long long)(2 * t + 1) * HWo + p];
-        m = msk[(long long)t * HWo + p];
-        if (a.mask_is_logit) m = 1.f / (1.f + __expf(-m));
-      }
-      const float py = (float)(ho * a.stride - a.pad + ky * a.dil) + oy;
-      const float px = (float)(wo * a.stride - a.pad + kx * a.dil) + ox;
+      float m = mk[t];
+      if (a.mask_is_logit) m = 1.f / (1.f + __expf(-m));
+      const float py = (float)(ho * a.stride - a.pad + ky * a.dil) + oy[t];
+      const float px = (float)(wo * a.stride - a.pad + kx * a.dil) + ox[t];
       const bool inside = p_ok && py > -1.f && px > -1.f && py < (float)a.H && px < (float)a.W;
       const float fy = floorf(py), fx = floorf(px);
       const int y0 = (int)fy, x0 = (int)fx;
@@ -85,16 +109,16 @@ __global__ __launch_bounds__(256) void dcn_fwd_kernel(DcnFwdArgs a) {
       const float hy = 1.f - ly, hx = 1.f - lx;
       const bool y0ok = y0 >= 0, y1ok = y0 + 1 <= a.H - 1;
       const bool x0ok = x0 >= 0, x1ok = x0 + 1 <= a.W - 1;
-      const int y0c = min(max(y0, 0), a.H - 1), y1c = min(max(y0 + 1, 0), a.H - 1);
-      const int x0c = min(max(x0, 0), a.W - 1), x1c = min(max(x0 + 1, 0), a.W - 1);
+      const int y0c = min(max(y0, 0), a.H - 1), x0c = min(max(x0, 0), a.W - 1);
       cw[t][0] = (inside && y0ok && x0ok) ? hy * hx * m : 0.f;
       cw[t][1] = (inside && y0ok && x1ok) ? hy * lx * m : 0.f;
       cw[t][2] = (inside && y1ok && x0ok) ? ly * hx * m : 0.f;
       cw[t][3] = (inside && y1ok && x1ok) ? ly * lx * m : 0.f;
-      ci[t][0] = inside ? y0c * a.W + x0c : 0;
-      ci[t][1] = inside ? y0c * a.W + x1c : 0;
-      ci[t][2] = inside ? y1c * a.W + x0c : 0;
-      ci[t][3] = inside ? y1c * a.W + x1c : 0;
+      cbase[t] = inside ? y0c * a.W + x0c : 0;
+      // a step is taken only when both ends are real pixels; otherwise the weight is 0
+      // and the read aliases a valid address
+      if (inside && x0ok && x1ok) cstep |= 1u << (2 * t);
+      if (inside && y0ok && y1ok) cstep |= 2u << (2 * t);
     }
   }
 
@@ -108,37 +132,80 @@ __global__ __launch_bounds__(256) void dcn_fwd_kernel(DcnFwdArgs a) {
   const int Ktot = a.Cin * TAPS;
   const float* xb = a.x + (long long)b * a.Cin * HW;
 
-  for (int c0 = 0; c0 < a.Cin; c0 += KC) {
-    __syncthreads();   // previous chunk's fragment reads are done
-    // ---- sample this wave's channels of the chunk ----
+  const int ksl = (a.splitk > 1) ? (int)(blockIdx.z / a.B) : 0;
+  const int c_begin = ksl * a.c_per_split;
+  const int c_end = min(a.Cin, c_begin + a.c_per_split);
+
+  // Software pipeline (register double-buffer): the gathers and the weight rows of
+  // chunk i+1 are ISSUED before chunk i's MFMA phase and only consumed after it, so
+  // their L2/HBM latency hides under the matrix work instead of adding to it.
+  constexpr int WPT = (BN * KK + 255) / 256;     // weight elements per thread per chunk
+  float g[CPW][TAPS][4];
+  float wreg[WPT];
+  auto issue_loads = [&](int c0) {
 #pragma unroll
-    for (int cc = 0; cc < CPW; ++cc) {
-      const int cl = wid * CPW + cc;
-      const int c = c0 + cl;
-      const bool c_ok = c < a.Cin;
-      const float* xc = xb + (long long)(c_ok ? c : 0) * HW;
-#pragma unroll
-      for (int t = 0; t < TAPS; ++t) {
-        float v = cw[t][0] * xc[ci[t][0]] + cw[t][1] * xc[ci[t][1]] +
-                  cw[t][2] * xc[ci[t][2]] + cw[t][3] * xc[ci[t][3]];
-        colT[lane * LD + cl * TAPS + t] = c_ok ? v : 0.f;
-      }
-    }
-    // ---- stage the weight chunk [BN][KK] ----
-    for (int idx = tid; idx < BN * KK; idx += 256) {
+    for (int i = 0; i < WPT; ++i) {
+      const int idx = tid + i * 256;
       const int co = idx / KK;
       const int kk = idx - co * KK;
       const int kg = c0 * TAPS + kk;
       float w = 0.f;
-      if (n0 + co < a.Cout && kg < Ktot) w = a.weight[(long long)(n0 + co) * Ktot + kg];
-      wT[co * LD + kk] = w;
+      if (!CP_ABL(4) && idx < BN * KK && n0 + co < a.Cout && kg < c_end * TAPS)
+        w = a.weight[(long long)(n0 + co) * Ktot + kg];
+      wreg[i] = w;
     }
+#pragma unroll
+    for (int cc = 0; cc < CPW; ++cc) {
+      const int c = c0 + wid * CPW + cc;
+      const float* xc = xb + (long long)(c < c_end ? c : c_begin) * HW;
+#pragma unroll
+      for (int t = 0; t < TAPS; ++t) {
+        if (CP_ABL(1)) {
+          g[cc][t][0] = g[cc][t][1] = g[cc][t][2] = g[cc][t][3] = 1.f;
+          continue;
+        }
+        const int dx = (cstep >> (2 * t)) & 1;
+        const int dy = ((cstep >> (2 * t + 1)) & 1) ? a.W : 0;
+        const float* q = xc + cbase[t];
+        g[cc][t][0] = q[0];
+        g[cc][t][1] = q[dx];
+        g[cc][t][2] = q[dy];
+        g[cc][t][3] = q[dy + dx];
+      }
+    }
+  };
+  auto write_lds = [&](int c0) {
+#pragma unroll
+    for (int cc = 0; cc < CPW; ++cc) {
+      const int cl = wid * CPW + cc;
+      const bool c_ok = c0 + cl < c_end;
+#pragma unroll
+      for (int t = 0; t < TAPS; ++t) {
+        const float v = cw[t][0] * g[cc][t][0] + cw[t][1] * g[cc][t][1] +
+                        cw[t][2] * g[cc][t][2] + cw[t][3] * g[cc][t][3];
+        if (!CP_ABL(2)) colT[lane * LD + cl * TAPS + t] = c_ok ? v : 0.f;
+        else if (v == 12345.f) colT[0] = v;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < WPT; ++i) {
+      const int idx = tid + i * 256;
+      if (idx < BN * KK) {
+        const int co = idx / KK;
+        wT[co * LD + (idx - co * KK)] = wreg[i];
+      }
+    }
+  };
+
+  if (c_begin < c_end) issue_loads(c_begin);
+  for (int c0 = c_begin; c0 < c_end; c0 += KC) {
+    write_lds(c0);                       // waits for this chunk's loads
     __syncthreads();
-    // ---- MFMA over the chunk ----
+    if (c0 + KC < c_end) issue_loads(c0 + KC);   // in flight during the MFMA phase
     const int arow = (wm * 32 + (lane & 15)) * LD + (lane >> 4);
     const int brow = (wn * (BN / 2) + (lane & 15)) * LD + (lane >> 4);
 #pragma unroll
-    for (int ks = 0; ks < KK / 4; ++ks) {
+    for (int ks = 0; ks < (CP_ABL(8) ? 0 : KK / 4); ++ks) {
       float af[2], bf[NT];
 #pragma unroll
       for (int i = 0; i < 2; ++i) af[i] = colT[arow + i * 16 * LD + ks * 4];
@@ -150,18 +217,23 @@ __global__ __launch_bounds__(256) void dcn_fwd_kernel(DcnFwdArgs a) {
         for (int j = 0; j < NT; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[j], acc[i][j], 0, 0, 0);
     }
+    __syncthreads();                     // fragment reads done before the next write_lds
   }
 
   // ---- epilogue: C layout col = lane&15 (cout), row = (lane>>4)*4 + reg (pixel) ----
-  float* ob = a.out + (long long)b * a.Cout * HWo;
+  const bool raw = a.splitk > 1;
+  float* ob = raw ? a.partial + ((long long)ksl * a.B + b) * a.Cout * HWo
+                  : a.out + (long long)b * a.Cout * HWo;
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
     const int co = n0 + wn * (BN / 2) + j * 16 + (lane & 15);
     if (co >= a.Cout) continue;
     float sc = 1.f, sh = 0.f;
-    if (a.ep_scale) sc = a.ep_scale[co];
-    if (a.ep_shift) sh = a.ep_shift[co];
-    else if (a.bias) sh = a.bias[co];
+    if (!raw) {
+      if (a.ep_scale) sc = a.ep_scale[co];
+      if (a.ep_shift) sh = a.ep_shift[co];
+      else if (a.bias) sh = a.bias[co];
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int pp = blockIdx.x * BM + wm * 32 + i * 16 + (lane >> 4) * 4;
@@ -169,7 +241,7 @@ __global__ __launch_bounds__(256) void dcn_fwd_kernel(DcnFwdArgs a) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         v[r] = acc[i][j][r] * sc + sh;
-        if (a.relu) v[r] = fmaxf(v[r], 0.f);
+        if (a.relu && !raw) v[r] = fmaxf(v[r], 0.f);
       }
       float* dst = ob + (long long)co * HWo + pp;
       if (pp + 3 < HWo && (HWo & 3) == 0) {
@@ -183,40 +255,119 @@ __global__ __launch_bounds__(256) void dcn_fwd_kernel(DcnFwdArgs a) {
   }
 }
 
-template <int BN, int KC>
+// Sum the K-split partials and apply bias / folded-BN / ReLU.
+__global__ __launch_bounds__(256) void dcn_splitk_reduce_kernel(DcnFwdArgs a, long long n_per_b) {
+  const long long total = (long long)a.B * n_per_b;
+  const int HWo = a.Ho * a.Wo;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total;
+       i += (long long)gridDim.x * 256) {
+    float v = 0.f;
+    for (int sidx = 0; sidx < a.splitk; ++sidx) v += a.partial[(long long)sidx * total + i];
+    const int co = (int)((i % n_per_b) / HWo);
+    float sc = 1.f, sh = 0.f;
+    if (a.ep_scale) sc = a.ep_scale[co];
+    if (a.ep_shift) sh = a.ep_shift[co];
+    else if (a.bias) sh = a.bias[co];
+    v = v * sc + sh;
+    if (a.relu) v = fmaxf(v, 0.f);
+    a.out[i] = v;
+  }
+}
+
+struct Plan {
+  int bn, splitk, c_per_split;
+};
+
+Plan make_plan(int B, int Cin, int Cout, int HWo) {
+  // Widest N tile that is not mostly padding: every extra N tile re-samples the
+  // columns.  Under-filled grids are topped up by splitting K, not by narrowing N.
+  const long long tiles_m = (long long)((HWo + BM - 1) / BM) * B;
+  Plan p;
+  p.bn = Cout > 128 ? 256 : (Cout > 64 ? 128 : 64);
+  const long long blocks = tiles_m * ((Cout + p.bn - 1) / p.bn);
+  p.splitk = 1;
+  const int kc = 4;
+  if (blocks < 384) {
+    int s = (int)((512 + blocks - 1) / blocks);
+    const int max_s = (Cin + 4 * kc - 1) / (4 * kc);    // keep >= 4 chunks per slice
+    if (s > max_s) s = max_s;
+    if (s > 16) s = 16;
+    if (s < 1) s = 1;
+    p.splitk = s;
+  }
+  int cps = (Cin + p.splitk - 1) / p.splitk;
+  cps = (cps + kc - 1) / kc * kc;
+  p.c_per_split = cps;
+  p.splitk = (Cin + cps - 1) / cps;
+  return p;
+}
+
+template <int BN, int KC, int WPS>
 int launch(const DcnFwdArgs& a, hipStream_t st) {
   constexpr int LD = KC * TAPS + 1;
   const size_t lds = (size_t)(BM + BN) * LD * sizeof(float);
-  dim3 grid((a.Ho * a.Wo + BM - 1) / BM, (a.Cout + BN - 1) / BN, a.B);
-  hipLaunchKernelGGL((dcn_fwd_kernel<BN, KC>), grid, dim3(256), lds, st, a);
+  dim3 grid((a.Ho * a.Wo + BM - 1) / BM, (a.Cout + BN - 1) / BN, a.B * a.splitk);
+  hipLaunchKernelGGL((dcn_fwd_kernel<BN, KC, WPS>), grid, dim3(256), lds, st, a);
+  if (a.splitk > 1) {
+    const long long n_per_b = (long long)a.Cout * a.Ho * a.Wo;
+    long long nb = ((long long)a.B * n_per_b + 255) / 256;
+    if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(dcn_splitk_reduce_kernel, dim3((unsigned)nb), dim3(256), 0, st, a, n_per_b);
+  }
   return cp_launch_status();
 }
 
+int out_extent(int in, int pad, int dil, int stride) {
+  return (in + 2 * pad - (dil * 2 + 1)) / stride + 1;
+}
+
 }  // namespace
+
+extern "C" size_t cp_dcn_v2_forward_workspace_bytes(const cp_dcn_shape* s) {
+  if (!s || s->B <= 0 || s->Cin <= 0 || s->Cout <= 0) return 0;
+  const int Ho = out_extent(s->H, s->pad, s->dil, s->stride);
+  const int Wo = out_extent(s->W, s->pad, s->dil, s->stride);
+  if (Ho <= 0 || Wo <= 0) return 0;
+  const Plan p = make_plan(s->B, s->Cin, s->Cout, Ho * Wo);
+  if (p.splitk <= 1) return 0;
+  return (size_t)p.splitk * s->B * s->Cout * Ho * Wo * sizeof(float);
+}
 
 extern "C" int cp_dcn_v2_forward(const cp_dcn_shape* s, const float* x, const float* offset,
                                  int64_t offset_bstride, const float* mask,
                                  int64_t mask_bstride, int32_t mask_is_logit,
                                  const float* weight, const float* bias, const float* ep_scale,
-                                 const float* ep_shift, int32_t relu, float* out, void* stream) {
+                                 const float* ep_shift, int32_t relu, float* out, void* workspace,
+                                 size_t workspace_bytes, void* stream) {
   CP_CHECK_ARG(s && x && offset && mask && weight && out);
   CP_CHECK_ARG(s->B > 0 && s->Cin > 0 && s->H > 0 && s->W > 0 && s->Cout > 0);
   CP_CHECK_ARG(s->stride > 0 && s->dil > 0 && s->pad >= 0);
   if (s->kh != 3 || s->kw != 3 || s->deformable_groups != 1) return CP_EUNSUPPORTED;
-  const int Ho = (s->H + 2 * s->pad - (s->dil * 2 + 1)) / s->stride + 1;
-  const int Wo = (s->W + 2 * s->pad - (s->dil * 2 + 1)) / s->stride + 1;
+  const int Ho = out_extent(s->H, s->pad, s->dil, s->stride);
+  const int Wo = out_extent(s->W, s->pad, s->dil, s->stride);
   CP_CHECK_ARG(Ho > 0 && Wo > 0);
   if ((long long)s->H * s->W >= (1ll << 31) || (long long)Ho * Wo >= (1ll << 31)) return CP_EUNSUPPORTED;
-  if (s->B > 65535) return CP_EUNSUPPORTED;
+  const Plan p = make_plan(s->B, s->Cin, s->Cout, Ho * Wo);
+  if ((long long)s->B * p.splitk > 65535) return CP_EUNSUPPORTED;
+  if (p.splitk > 1) {
+    if (!workspace || workspace_bytes < cp_dcn_v2_forward_workspace_bytes(s)) return CP_EWORKSPACE;
+  }
   DcnFwdArgs a;
   a.x = x; a.offset = offset; a.mask = mask; a.weight = weight; a.bias = bias;
-  a.ep_scale = ep_scale; a.ep_shift = ep_shift; a.out = out;
+  a.ep_scale = ep_scale; a.ep_shift = ep_shift; a.out = out; a.partial = (float*)workspace;
   a.offset_bstride = offset_bstride; a.mask_bstride = mask_bstride;
   a.B = s->B; a.Cin = s->Cin; a.H = s->H; a.W = s->W; a.Cout = s->Cout; a.Ho = Ho; a.Wo = Wo;
   a.stride = s->stride; a.pad = s->pad; a.dil = s->dil;
   a.mask_is_logit = mask_is_logit; a.relu = relu;
+  a.splitk = p.splitk; a.c_per_split = p.c_per_split;
+#ifdef CP_ABLATE
+  {
+    const char* e = getenv("CP_DCN_ABLATE");
+    a.ablate = e ? atoi(e) : 0;
+  }
+#endif
   hipStream_t st = (hipStream_t)stream;
-  if (s->Cout <= 64) return launch<64, 8>(a, st);
-  if (s->Cout <= 128) return launch<128, 8>(a, st);
-  return launch<256, 4>(a, st);
+  if (p.bn == 64) return launch<64, 4, 2>(a, st);
+  if (p.bn == 128) return launch<128, 4, 1>(a, st);
+  return launch<256, 4, 1>(a, st);
 }

@@ -2,13 +2,6 @@
 // They fail loudly (CP_EUNSUPPORTED) -- there is no fallback behind them.
 #include "cp_common.h"
 
-extern "C" size_t cp_dcn_v2_backward_workspace_bytes(const cp_dcn_shape*) { return 0; }
-extern "C" int cp_dcn_v2_backward(const cp_dcn_shape*, const float*, const float*, int64_t,
-                                  const float*, int64_t, int32_t, const float*, const float*,
-                                  float*, float*, int64_t, float*, int64_t, float*, float*, void*,
-                                  size_t, void*) {
-  return CP_EUNSUPPORTED;
-}
 extern "C" size_t cp_poly_iou_order_workspace_bytes(int32_t, int32_t, int32_t) { return 0; }
 extern "C" int cp_poly_iou_order_forward(const float*, const int64_t*, const uint8_t*, const float*,
                                          int32_t, int32_t, int32_t, int32_t, int32_t, int32_t,

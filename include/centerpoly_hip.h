@@ -86,6 +86,8 @@ const char* cp_build_arch(void);
  * Optional fused epilogue (inference): out = act(acc * ep_scale[co] + ep_shift[co])
  * with ep_scale/ep_shift NULL meaning scale 1 / shift = bias; relu != 0 clamps at 0.
  * When ep_scale/ep_shift are given, bias must already be folded into ep_shift.
+ * Small-spatial layers split K over workgroups; their partial sums live in the
+ * caller's workspace (cp_dcn_v2_forward_workspace_bytes, may be 0 / NULL).
  */
 typedef struct cp_dcn_shape {
   int32_t B, Cin, H, W, Cout;
@@ -93,11 +95,12 @@ typedef struct cp_dcn_shape {
   int32_t deformable_groups; /* only 1 is implemented */
 } cp_dcn_shape;
 
+size_t cp_dcn_v2_forward_workspace_bytes(const cp_dcn_shape* s); /* 0 for most shapes */
 int cp_dcn_v2_forward(const cp_dcn_shape* s, const float* x, const float* offset,
                       int64_t offset_bstride, const float* mask, int64_t mask_bstride,
                       int32_t mask_is_logit, const float* weight, const float* bias,
                       const float* ep_scale, const float* ep_shift, int32_t relu, float* out,
-                      void* stream);
+                      void* workspace, size_t workspace_bytes, void* stream);
 
 /* Backward.  grad_* outputs may be NULL to skip that gradient.  grad_x,
  * grad_weight and grad_bias are ACCUMULATED INTO (caller zero-fills);

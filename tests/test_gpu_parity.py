@@ -279,6 +279,86 @@ def test_dcn_fused_bn_relu_epilogue():
     np.testing.assert_allclose(fused.cpu().numpy(), plain.cpu().numpy(), rtol=1e-4, atol=1e-5)
 
 
+DCN_BWD_SHAPES = [(1, 16, 24, 12, 20), (2, 8, 140, 9, 11), (1, 64, 64, 16, 32), (1, 130, 32, 8, 8)]
+
+
+@pytest.mark.parametrize("shape", DCN_BWD_SHAPES, ids=lambda s: "x".join(map(str, s)))
+def test_dcn_backward_vs_oracle_autograd(shape):
+    """grad_input, grad_offset, grad_mask(logit), grad_weight, grad_bias vs torch autograd
+    through the oracle's DCN (the `DCN` module path: conv_offset_mask output `om` is a leaf)."""
+    from centerpoly_amd.models.networks.DCNv2.dcn_v2 import _DCNv2Function
+    B, Cin, Cout, H, W = shape
+    x, om, w, b = _dcn_inputs("bwd%dx%d" % (Cin, Cout), *shape)
+    gout = synth.normal("dcn/bwd/go%dx%d" % (Cin, Cout), (B, Cout, H, W))
+    tx, tom, tw, tb = (T(v).requires_grad_(True) for v in (x, om, w, b))
+    o1, o2, m = torch.chunk(tom, 3, dim=1)
+    ref = odcn.dcn_v2_forward(tx, torch.cat((o1, o2), 1), torch.sigmoid(m), tw, tb)
+    ref.backward(T(gout))
+    dx, dom, dw, db = (g(v).requires_grad_(True) for v in (x, om, w, b))
+    out = _DCNv2Function.apply(dx, dom, dw, db, 1, 1, 1, 1)
+    out.backward(g(gout))
+    for name, got, want in (("x", dx.grad, tx.grad), ("om", dom.grad, tom.grad),
+                            ("w", dw.grad, tw.grad), ("b", db.grad, tb.grad)):
+        scale = want.abs().max().item()
+        np.testing.assert_allclose(got.cpu().numpy(), want.numpy(), rtol=1e-3, atol=2e-5 * scale,
+                                   err_msg="grad_" + name)
+
+
+def test_dcn_backward_finite_difference():
+    """Independent of the oracle: central differences on a scalar loss through the HIP forward."""
+    from centerpoly_amd.models.networks.DCNv2.dcn_v2 import _DCNv2Function, dcn_v2_forward_raw
+    B, Cin, Cout, H, W = 1, 6, 5, 7, 9
+    x, om, w, b = _dcn_inputs("fd", B, Cin, Cout, H, W, offset_scale=0.7)
+    om[:, :18] += 0.37                       # keep samples away from integer positions (kinks)
+    gout = synth.normal("dcn/fd/go", (B, Cout, H, W))
+    dx, dom, dw, db = (g(v).double().float().requires_grad_(True) for v in (x, om, w, b))
+    _DCNv2Function.apply(dx, dom, dw, db, 1, 1, 1, 1).backward(g(gout))
+
+    def loss(xx, oo):
+        return (dcn_v2_forward_raw(xx, oo, g(w), g(b)).double() * g(gout).double()).sum().item()
+
+    eps = 2e-3
+    # perturb only offsets whose sample coordinate stays clear of integer positions (kinks of
+    # the bilinear interpolant), mask logits anywhere
+    ch, hh, ww = np.unravel_index(np.arange(om.size), om.shape[1:])
+    tap = np.where(ch < 18, ch // 2, 0)
+    base = np.where(ch % 2 == 0, hh - 1 + tap // 3, ww - 1 + tap % 3)
+    coord = base + om.reshape(-1)
+    frac = coord - np.floor(coord)
+    safe = (ch >= 18) | ((frac > 0.05) & (frac < 0.95))
+    cand = np.nonzero(safe)[0]
+    idxs = cand[synth.integers("dcn/fd/idx", (8,), 0, cand.size)]
+    for flat in idxs:
+        d = np.zeros(om.size, np.float32)
+        d[flat] = eps
+        d = d.reshape(om.shape)
+        num = (loss(g(x), g(om + d)) - loss(g(x), g(om - d))) / (2 * eps)
+        ana = dom.grad.cpu().numpy().reshape(-1)[flat]
+        assert abs(num - ana) <= 2e-2 * max(1.0, abs(ana)), (flat, num, ana)
+
+
+def test_deformconv_training_path_backward():
+    """DeformConv (DCN -> BN -> ReLU) in train mode: parameter grads exist and match the oracle."""
+    from centerpoly_amd.models.networks.pose_dla_dcn import DeformConv
+    m = DeformConv(16, 24).to(DEV).train()
+    sd = {k: T(v) for k, v in cases.fill_weights({k: tuple(v.shape) for k, v in m.state_dict().items()}).items()}
+    m.load_state_dict(sd)
+    x = synth.normal("dcn/train/x", (2, 16, 10, 14))
+    y = m(g(x))
+    y.square().mean().backward()
+    # oracle
+    p = {k: v.clone().requires_grad_(True) for k, v in sd.items() if v.is_floating_point()}
+    yo = odcn.dcn_module_forward(T(x), p["conv.weight"], p["conv.bias"], p["conv.conv_offset_mask.weight"],
+                                 p["conv.conv_offset_mask.bias"])
+    yo = torch.relu(torch.nn.functional.batch_norm(yo, None, None, p["actf.0.weight"], p["actf.0.bias"], True))
+    yo.square().mean().backward()
+    np.testing.assert_allclose(y.detach().cpu().numpy(), yo.detach().numpy(), rtol=1e-3, atol=1e-5)
+    for k, v in m.named_parameters():
+        want = p[k].grad
+        np.testing.assert_allclose(v.grad.cpu().numpy(), want.numpy(), rtol=2e-3,
+                                   atol=3e-5 * want.abs().max().item(), err_msg=k)
+
+
 # ------------------------------------------------------------------- nets ---
 
 def _load_by_name(model, gold):

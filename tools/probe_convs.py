@@ -21,7 +21,7 @@ shapes = [  # Cin, Cout, k, stride, H, W (input)
     (256, 8, 1, 1, 256, 512),
 ]
 print("torch", torch.__version__, torch.cuda.get_device_name(0))
-for (ci, co, k, s, H, W) in shapes:
+for (ci, co, k, s, H, W) in (shapes if "--convs" in sys.argv else []):
     gf = 2 * ci * co * k * k * (H // s) * (W // s) / 1e9
     row = "%4d->%4d k%d s%d @%4dx%4d %7.2f GF |" % (ci, co, k, s, H, W, gf)
     for dt, cl in ((torch.float32, False), (torch.float32, True), (torch.bfloat16, False), (torch.bfloat16, True), (torch.float16, True)):
