@@ -186,6 +186,100 @@ def test_polyloss_l1_variants_vs_golden(case, golden):
     np.testing.assert_allclose(o.grad.abs().double().sum().item(), gold["grad_abs_sum"], rtol=1e-4)
 
 
+IOU_ORDER = [c for c in cases.POLY_CASES if c[6] != "l1" or c[7]]
+
+
+@pytest.mark.parametrize("case", IOU_ORDER, ids=lambda c: c[0])
+def test_polyloss_iou_and_order_vs_reference_golden(case, golden):
+    """Weiler-Atherton IoU and order terms (HIP) vs values AND gradients recorded from the
+    reference's PolyLoss (autograd through its Python clipper)."""
+    from centerpoly_amd.models.losses import PolyLoss
+    name, B, h, w, N, rep, pl, order = case
+    gold = golden("loss_poly_" + name)
+    batch, out = cases.loss_batch(name, B, h, w, N, rep)
+    o = g(out["poly"]).requires_grad_(True)
+    r = PolyLoss(_Opt(poly_loss=pl, rep=rep, poly_order=order))(
+        o, g(batch["reg_mask"]), g(batch["ind"]), g(batch["poly"]))
+    if order:
+        np.testing.assert_allclose(r[1].item(), gold["order"], rtol=1e-4, atol=1e-6)
+        total, main = r[0] + r[1], r[0]
+    else:
+        total = main = r
+    np.testing.assert_allclose(main.item(), gold["loss"], rtol=1e-3, atol=1e-5)
+    total.backward()
+    idx = g(batch["ind"])
+    rows = torch.gather(o.grad.view(B, 2 * N, -1), 2, idx.unsqueeze(1).expand(B, 2 * N, idx.shape[1]))
+    scale = np.abs(gold["grad_rows"]).max()
+    np.testing.assert_allclose(rows.cpu().numpy(), gold["grad_rows"], rtol=2e-3, atol=2e-4 * scale)
+    np.testing.assert_allclose(o.grad.abs().double().sum().item(), gold["grad_abs_sum"], rtol=1e-3)
+
+
+def _single_object_iou(subject, clip):
+    """IoU of one (subject, clip) pair through the kernel: B = M = 1, loss = 1 - iou/(1+1e-6)."""
+    from centerpoly_amd.models.losses import PolyLoss
+    N = subject.shape[0]
+    feat = torch.zeros((1, 2 * N, 2, 2))
+    feat[0, :, 1, 0] = T(subject.reshape(-1))
+    l = PolyLoss(_Opt(poly_loss="iou", rep="polar", poly_order=False))(
+        g(feat), torch.ones((1, 1), dtype=torch.uint8, device=DEV),
+        torch.full((1, 1), 2, dtype=torch.int64, device=DEV), g(clip.reshape(1, 1, -1)))
+    return (1.0 - l.item()) * (1.0 + 1e-6)
+
+
+def test_weiler_atherton_known_answers_on_gpu(golden):
+    gk = golden("wa_kats")
+    for n in ("same16", "inside", "rot015", "contains"):
+        # the kernel sorts its subject by theta; these subjects are already sorted
+        iou = _single_object_iou(gk[n + "_subject"], gk[n + "_clip"])
+        np.testing.assert_allclose(iou, gk[n + "_iou"], rtol=1e-4, err_msg=n)
+
+
+def test_polyloss_many_random_objects_vs_oracle():
+    """A larger population of objects (cartesian read as polar = spirals, and genuine polar
+    stars) against the oracle's literal Python clipper: values and gradients."""
+    from centerpoly_amd.models.losses import PolyLoss
+    for rep, tag in (("polar", "rndp"), ("cartesian", "rndc")):
+        batch, out = cases.loss_batch(tag, 2, 24, 40, 16, rep, mean_objs=12)
+        args = (T(batch["reg_mask"]), T(batch["ind"]), T(batch["poly"]))
+        oc = T(out["poly"]).requires_grad_(True)
+        ref = olos.poly_loss(oc, *args, "l1+iou", rep, False)
+        ref.backward()
+        od = g(out["poly"]).requires_grad_(True)
+        l = PolyLoss(_Opt(poly_loss="l1+iou", rep=rep, poly_order=False))(od, *(g(a) for a in args))
+        l.backward()
+        np.testing.assert_allclose(l.item(), ref.item(), rtol=1e-3, atol=1e-5)
+        gs = oc.grad.abs().max().item()
+        np.testing.assert_allclose(od.grad.cpu().numpy(), oc.grad.numpy(), rtol=2e-3, atol=2e-4 * gs)
+
+
+def test_polydet_loss_end_to_end_vs_oracle():
+    """PolydetLoss (trains/polydet.py) on raw head outputs: total, every stat and the
+    gradient w.r.t. every head, config-3 flavour (cartesian, l1+iou)."""
+    from centerpoly_amd.trains.polydet import PolydetLoss
+    batch, out = cases.loss_batch("e2e", 2, 32, 48, 16, "cartesian", mean_objs=6)
+    opt = _Opt(num_stacks=1, poly_loss="l1+iou", rep="cartesian", poly_order=False, hm_weight=1.0,
+               off_weight=1.0, poly_weight=1.0, depth_weight=0.1, reg_offset=True, reg_loss="l1",
+               task="polydet")
+    heads_c = {k: T(v).requires_grad_(True) for k, v in out.items()}
+    bt = {k: T(v) for k, v in batch.items()}
+    ref, rstats = olos.polydet_loss([heads_c], bt, poly_loss_kind="l1+iou", rep="cartesian")
+    ref.backward()
+    leaf = {k: g(v).requires_grad_(True) for k, v in out.items()}
+    heads_d = {k: v * 1.0 for k, v in leaf.items()}          # non-leaf, like a conv output
+    loss, stats = PolydetLoss(opt)([heads_d], {k: g(v) for k, v in batch.items()})
+    loss.backward()
+    np.testing.assert_allclose(loss.item(), ref.item(), rtol=1e-3)
+    for k in rstats:
+        np.testing.assert_allclose(float(stats[k]), float(rstats[k]), rtol=1e-3, atol=1e-6, err_msg=k)
+    for k in out:
+        want = heads_c[k].grad
+        np.testing.assert_allclose(leaf[k].grad.cpu().numpy(), want.numpy(), rtol=2e-3,
+                                   atol=2e-4 * want.abs().max().item(), err_msg=k)
+    # the reference mutates output['hm'] into the activated map
+    np.testing.assert_allclose(heads_d["hm"].detach().cpu().numpy(),
+                               olos.sigmoid_clamp(T(out["hm"])).numpy(), rtol=1e-5, atol=1e-7)
+
+
 def test_gather_l1_duplicate_centres_accumulate():
     from centerpoly_amd.models.losses import RegL1Loss
     feat = g(synth.normal("dup/f", (1, 2, 8, 8))).requires_grad_(True)
