@@ -102,3 +102,29 @@ def stream():
 
 def workspace(nbytes, device):
     return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
+
+
+class KernelTimer(object):
+    """Optional per-launch HIP-event timing on torch's current stream (where every kernel of
+    this library is launched).  bench.py enables it around the timed region to get the
+    dominant kernel's average launch duration; disabled (None) it costs nothing."""
+
+    def __init__(self):
+        self.records = {}
+
+    def start(self, key):
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        self.records.setdefault(key, []).append(ev)
+        ev[0].record()
+        return ev[1]
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for key, evs in self.records.items():
+            ms = [a.elapsed_time(b) for a, b in evs]
+            out[key] = {"launches": len(ms), "avg_ms": sum(ms) / len(ms), "min_ms": min(ms)}
+        return out
+
+
+kernel_timer = None
