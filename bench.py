@@ -24,6 +24,13 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+# MIOpen compiles its convolution kernels on first use (minutes on a fresh box).  Keep its
+# compiled-kernel cache inside the repo so it travels with the tree like our own .so.
+_MIOPEN_CACHE = os.path.join(ROOT, ".miopen_cache")
+os.environ.setdefault("MIOPEN_CUSTOM_CACHE_DIR", _MIOPEN_CACHE)
+os.environ.setdefault("MIOPEN_USER_DB_PATH", os.path.join(_MIOPEN_CACHE, "db"))
+os.makedirs(os.environ["MIOPEN_USER_DB_PATH"], exist_ok=True)
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -61,6 +68,8 @@ def build_model(dev, train):
     model.load_state_dict(sd)
     model = model.to(dev)
     model.train(train)
+    if not train and dev.type == "cuda":
+        model.prepare_inference()
     return model, sd
 
 
@@ -172,15 +181,16 @@ def train_leg(args, dev, world, rank, steps, warmup):
 
 
 def cpu_baseline(args):
-    """The CPU oracle (a port of the reference's path) on a bounded sample: one image at
-    1/4 of the pixels (half height, half width) through DLA-34 + DCN + decode."""
+    """The CPU oracle (a port of the reference's path) on a bounded sample: ONE full-size
+    image through DLA-34 + DCNv2 + decode (a few seconds on a 16-core host share)."""
     from centerpoly_amd import synth
     from oracle import decode as odec
     from oracle import nets as onet
-    threads = os.cpu_count() or 1
+    # a one-GPU box owns a 16-core share of the host: more threads only oversubscribe it
+    threads = min(os.cpu_count() or 1, 16)
     torch.set_num_threads(threads)
     note("cpu baseline (oracle on %d threads) ..." % threads)
-    h, w = args.height // 2, args.width // 2
+    h, w = args.height, args.width
     _, sd = build_model(torch.device("cpu"), train=False)
     x = torch.from_numpy(synth.normal("bench/cpu/input", (1, 3, h, w)))
     t0 = time.perf_counter()
@@ -188,9 +198,9 @@ def cpu_baseline(args):
         out = onet.dla_seg_forward(sd, x, dict(HEADS))[0]
         odec.polydet_decode(torch.sigmoid(out["hm"]), out["poly"], out["pseudo_depth"], out["reg"], K=128)
     t = time.perf_counter() - t0
-    return {"value": 0.25 / t, "unit": "img/s", "cores": threads, "kind": "port",
-            "sample": "1 image at %dx%d (1/4 of the %dx%d pixels, rate scaled by area), oracle "
-                      "DLA-34+DCNv2 forward + decode, %.1f s" % (w, h, args.width, args.height, t)}
+    return {"value": 1.0 / t, "unit": "img/s", "cores": threads, "kind": "port",
+            "sample": "1 image at %dx%d through the oracle's DLA-34+DCNv2 forward + sigmoid + "
+                      "decode, %.1f s wall" % (w, h, t)}
 
 
 def main():

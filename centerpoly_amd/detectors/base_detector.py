@@ -60,6 +60,8 @@ class BaseDetector(object):
             self.model = load_model(self.model, opt.load_model)
         self.model = self.model.to(opt.device)
         self.model.eval()
+        if hasattr(self.model, "prepare_inference"):
+            self.model.prepare_inference()      # BN folded into convs / the DCN epilogue
         self.mean = np.array(opt.mean, dtype=np.float32).reshape(1, 1, 3)
         self.std = np.array(opt.std, dtype=np.float32).reshape(1, 1, 3)
         self.max_per_image = opt.K

@@ -14,6 +14,7 @@ import math
 
 import numpy as np
 import torch
+import torch.nn.functional as F
 from torch import nn
 
 from .DCNv2.dcn_v2 import DCN
@@ -23,6 +24,30 @@ BN_MOMENTUM = 0.1
 
 def _bn(c):
     return nn.BatchNorm2d(c, momentum=BN_MOMENTUM)
+
+
+# ---- inference-time BatchNorm folding --------------------------------------------------
+# prepare_inference() caches, per (conv, bn) pair, the conv weight scaled by
+# gamma/sqrt(var+eps) and the matching bias, so eval-mode forward runs conv(+bias)+ReLU with
+# no BatchNorm pass; DeformConv gets the same affine in the DCN kernel's epilogue.  The cache
+# is dropped by train(); checkpoints / state_dict are untouched.
+
+def _fold_conv_bn(conv, bn):
+    with torch.no_grad():
+        scale = bn.weight * torch.rsqrt(bn.running_var + bn.eps)
+        w = (conv.weight * scale.view(-1, 1, 1, 1)).contiguous()
+        b = bn.bias - bn.running_mean * scale
+        if conv.bias is not None:
+            b = b + conv.bias * scale
+    return w, b.contiguous()
+
+
+def _use_folded(m):
+    return getattr(m, "_folded", None) is not None and not m.training and not torch.is_grad_enabled()
+
+
+def _conv_folded(x, conv, wb):
+    return F.conv2d(x, wb[0], wb[1], conv.stride, conv.padding, conv.dilation, conv.groups)
 
 
 class BasicBlock(nn.Module):
@@ -35,8 +60,16 @@ class BasicBlock(nn.Module):
         self.bn2 = _bn(planes)
         self.stride = stride
 
+    def fold(self):
+        self._folded = (_fold_conv_bn(self.conv1, self.bn1), _fold_conv_bn(self.conv2, self.bn2))
+
     def forward(self, x, residual=None):
         skip = x if residual is None else residual
+        if _use_folded(self):
+            y = F.relu_(_conv_folded(x, self.conv1, self._folded[0]))
+            y = _conv_folded(y, self.conv2, self._folded[1])
+            y += skip
+            return F.relu_(y)
         y = self.relu(self.bn1(self.conv1(x)))
         y = self.bn2(self.conv2(y))
         y += skip
@@ -51,7 +84,15 @@ class Root(nn.Module):
         self.relu = nn.ReLU(inplace=True)
         self.residual = residual
 
+    def fold(self):
+        self._folded = _fold_conv_bn(self.conv, self.bn)
+
     def forward(self, *xs):
+        if _use_folded(self):
+            y = _conv_folded(torch.cat(xs, 1), self.conv, self._folded)
+            if self.residual:
+                y += xs[0]
+            return F.relu_(y)
         y = self.bn(self.conv(torch.cat(xs, 1)))
         if self.residual:
             y += xs[0]
@@ -85,10 +126,19 @@ class Tree(nn.Module):
             self.project = nn.Sequential(nn.Conv2d(in_channels, out_channels, 1, 1, bias=False),
                                          _bn(out_channels))
 
+    def fold(self):
+        self._folded = _fold_conv_bn(self.project[0], self.project[1]) if self.project is not None \
+            else None
+
     def forward(self, x, residual=None, children=None):
         children = [] if children is None else children
         bottom = x if self.downsample is None else self.downsample(x)
-        residual = bottom if self.project is None else self.project(bottom)
+        if self.project is None:
+            residual = bottom
+        elif _use_folded(self):
+            residual = _conv_folded(bottom, self.project[0], self._folded)
+        else:
+            residual = self.project(bottom)
         if self.level_root:
             children.append(bottom)
         x1 = self.tree1(x, residual)
@@ -121,10 +171,25 @@ class DLA(nn.Module):
             inplanes = planes
         return nn.Sequential(*mods)
 
+    def fold(self):
+        seqs = (self.base_layer, self.level0, self.level1)
+        if any(len(seq) != 3 for seq in seqs):        # multi-conv levels: keep the plain path
+            self._folded = None
+            return
+        self._folded = [_fold_conv_bn(seq[0], seq[1]) for seq in seqs]
+
     def forward(self, x):
-        x = self.base_layer(x)
         pyramid = []
-        for i in range(6):
+        if _use_folded(self):
+            for seq, wb in zip((self.base_layer, self.level0, self.level1), self._folded):
+                x = F.relu_(_conv_folded(x, seq[0], wb))
+                if seq is not self.base_layer:
+                    pyramid.append(x)
+            first_tree = 2
+        else:
+            x = self.base_layer(x)
+            first_tree = 0
+        for i in range(first_tree, 6):
             x = getattr(self, "level%d" % i)(x)
             pyramid.append(x)
         return pyramid
@@ -175,9 +240,14 @@ class DeformConv(nn.Module):
         shift = (self.conv.bias - bn.running_mean) * scale + bn.bias
         return scale.contiguous(), shift.contiguous()
 
+    def fold(self):
+        with torch.no_grad():
+            self._folded = self.folded_affine()
+
     def forward(self, x):
         if not self.training and not torch.is_grad_enabled():
-            scale, shift = self.folded_affine()
+            scale, shift = self._folded if getattr(self, "_folded", None) is not None \
+                else self.folded_affine()
             return self.conv.forward_fused(x, scale, shift, relu=True)
         return self.actf(self.conv(x))
 
@@ -254,6 +324,22 @@ class DLASeg(nn.Module):
             else:
                 fill_fc_weights(fc)
             self.__setattr__(head, fc)
+
+    def prepare_inference(self):
+        """Fold every BatchNorm into its convolution / DCN epilogue (call after loading weights,
+        in eval mode).  Undone by train()."""
+        self.eval()
+        for m in self.modules():
+            if hasattr(m, "fold"):
+                m.fold()
+        return self
+
+    def train(self, mode=True):
+        if mode:
+            for m in self.modules():
+                if hasattr(m, "_folded"):
+                    m._folded = None
+        return super().train(mode)
 
     def forward(self, x):
         x = self.dla_up(self.base(x))
