@@ -17,6 +17,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
+from ... import _C
 from .DCNv2.dcn_v2 import DCN
 
 BN_MOMENTUM = 0.1
@@ -252,6 +253,19 @@ class DeformConv(nn.Module):
         return self.actf(self.conv(x))
 
 
+def depthwise_up_add(x, up, skip):
+    """up(x) + skip in one HIP kernel (inference): `up` is IDAUp's depth-wise ConvTranspose2d."""
+    L = _C.lib()
+    B, C, H, W = x.shape
+    f = up.stride[0]
+    out = torch.empty((B, C, H * f, W * f), dtype=torch.float32, device=x.device)
+    x, skip = x.contiguous(), skip.contiguous()
+    rc = L.cp_depthwise_up_forward(_C.ptr(x), _C.ptr(up.weight), _C.ptr(skip), _C.ptr(out), B, C, H,
+                                   W, f, _C.stream())
+    _C.check(rc, "cp_depthwise_up_forward")
+    return out
+
+
 class IDAUp(nn.Module):
     def __init__(self, o, channels, up_f):
         super().__init__()
@@ -265,10 +279,16 @@ class IDAUp(nn.Module):
             setattr(self, "node_%d" % i, DeformConv(o, o))
 
     def forward(self, layers, startp, endp):
+        fused = not self.training and not torch.is_grad_enabled()
         for i in range(startp + 1, endp):
             k = i - startp
-            up = getattr(self, "up_%d" % k)(getattr(self, "proj_%d" % k)(layers[i]))
-            layers[i] = getattr(self, "node_%d" % k)(up + layers[i - 1])
+            up, proj = getattr(self, "up_%d" % k), getattr(self, "proj_%d" % k)
+            if fused and layers[i].is_cuda and up.stride[0] in (2, 4, 8) \
+                    and (layers[i].shape[3] * up.stride[0]) % 4 == 0:
+                summed = depthwise_up_add(proj(layers[i]), up, layers[i - 1])
+            else:
+                summed = up(proj(layers[i])) + layers[i - 1]
+            layers[i] = getattr(self, "node_%d" % k)(summed)
 
 
 class DLAUp(nn.Module):

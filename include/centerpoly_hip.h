@@ -19,6 +19,9 @@
  *       dcn_v2_forward(input, weight, bias, offset, mask, kh,kw, sh,sw, ph,pw,
  *       dh,dw, dg) and dcn_v2_backward(..., grad_output) -> (grad_input,
  *       grad_offset, grad_mask, grad_weight, grad_bias).
+ *   cp_depthwise_up_forward
+ *       IDAUp's depth-wise ConvTranspose2d `up` + skip add,
+ *       src/lib/models/networks/pose_dla_dcn.py:372-375, 381-387.
  *   cp_polydet_decode
  *       _nms + _topk + polydet_decode, src/lib/models/decode.py:13-19, 117-133,
  *       512-670, and the gather helpers src/lib/models/utils.py:12-26.
@@ -113,6 +116,15 @@ int cp_dcn_v2_backward(const cp_dcn_shape* s, const float* x, const float* offse
                        float* grad_x, float* grad_offset, int64_t grad_offset_bstride,
                        float* grad_mask, int64_t grad_mask_bstride, float* grad_weight,
                        float* grad_bias, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------- depth-wise up-sampling --
+ * IDAUp's `up` (depth-wise ConvTranspose2d, kernel 2f, stride f, padding f/2,
+ * groups = C, no bias; src/lib/models/networks/pose_dla_dcn.py:372-375) fused with
+ * the `+ layers[i-1]` that follows it (:381-387).
+ *   x [B,C,H,W], weight [C,1,2f,2f], skip [B,C,H*f,W*f] or NULL -> out [B,C,H*f,W*f]
+ * f in {2,4,8}.  Forward only (training keeps the autograd path). */
+int cp_depthwise_up_forward(const float* x, const float* weight, const float* skip, float* out,
+                            int32_t B, int32_t C, int32_t H, int32_t W, int32_t f, void* stream);
 
 /* ----------------------------------------------------------------- decode --
  * heat [B,C,H,W] (already activated), polys [B,2N,H,W], depth [B,1,H,W],

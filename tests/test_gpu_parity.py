@@ -457,6 +457,20 @@ def test_deformconv_training_path_backward():
                                    atol=3e-5 * want.abs().max().item(), err_msg=k)
 
 
+@pytest.mark.parametrize("f,C,H,W", [(2, 64, 16, 24), (4, 8, 9, 11), (8, 5, 6, 7), (2, 3, 5, 6)])
+def test_depthwise_up_add_vs_conv_transpose(f, C, H, W):
+    from centerpoly_amd.models.networks.pose_dla_dcn import depthwise_up_add, fill_up_weights
+    up = torch.nn.ConvTranspose2d(C, C, f * 2, stride=f, padding=f // 2, groups=C, bias=False)
+    fill_up_weights(up)
+    with torch.no_grad():
+        up.weight.add_(T(synth.normal("up/w%d" % f, tuple(up.weight.shape), 0, 0.05)))   # trainable
+        x = T(synth.normal("up/x%d" % f, (2, C, H, W)))
+        skip = T(synth.normal("up/s%d" % f, (2, C, H * f, W * f)))
+        ref = up(x) + skip
+        out = depthwise_up_add(g(x), up.to(DEV), g(skip)).cpu()
+    np.testing.assert_allclose(out.numpy(), ref.numpy(), rtol=1e-5, atol=1e-6)
+
+
 # ------------------------------------------------------------------- nets ---
 
 def _load_by_name(model, gold):
