@@ -373,7 +373,9 @@ def test_dcn_fused_bn_relu_epilogue():
     np.testing.assert_allclose(fused.cpu().numpy(), plain.cpu().numpy(), rtol=1e-4, atol=1e-5)
 
 
-DCN_BWD_SHAPES = [(1, 16, 24, 12, 20), (2, 8, 140, 9, 11), (1, 64, 64, 16, 32), (1, 130, 32, 8, 8)]
+DCN_BWD_SHAPES = [(1, 16, 24, 12, 20), (2, 8, 140, 9, 11), (1, 64, 64, 16, 32), (1, 130, 32, 8, 8),
+                  # W % 64 == 0 -> LDS-region (tiled) data kernel, all three Cout tiles
+                  (1, 16, 24, 6, 64), (2, 10, 70, 5, 128), (1, 6, 200, 4, 64), (1, 64, 64, 9, 192)]
 
 
 @pytest.mark.parametrize("shape", DCN_BWD_SHAPES, ids=lambda s: "x".join(map(str, s)))
