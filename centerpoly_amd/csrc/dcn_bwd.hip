@@ -602,21 +602,190 @@ __global__ __launch_bounds__(256) void dcn_bwd_weight_kernel(DcnBwdArgs a) {
   }
 }
 
-// grad_bias[co] += sum_{b,p} go[b][co][p]; one workgroup per output channel.
+// ------------------------------------------------------ tiled weight kernel ---
+// One workgroup = (group of T consecutive 64-pixel tiles of one image) x (slice of WSC input
+// channels) x (slab of 128 output channels).  The gW tile [128 co][WSC*9] stays in registers
+// across all T tiles and is flushed with float atomics ONCE (T x fewer atomics than a flush per
+// tile); corners come from the LDS-staged input region (coalesced row loads, prefetched one
+// chunk ahead), with a global-gather fallback for taps that leave the region.
+constexpr int WSC = 16;                   // input channels per workgroup
+constexpr int WCH = WSC / KC;             // chunks per workgroup (4)
+
+struct WTiledExtra {
+  int T;                                  // tiles per group
+  int groups_per_image;
+};
+
+template <int SLAB, int WPS>                // output channels per workgroup: 64 or 128
+__global__ __launch_bounds__(256, WPS) void dcn_bwd_weight_tiled_kernel(DcnBwdArgs a, WTiledExtra ex) {
+  constexpr int MT = SLAB / 64;            // 16-row m-tiles per wave
+  constexpr int LDS_ = SLAB + 1;
+  extern __shared__ float lds[];
+  float* goT = lds;                       // [BM][LDS_]
+  float* colT = goT + BM * LDS_;           // [BM][LDW2]  columns of one chunk, padded to 48
+  constexpr int LDW2 = 49;
+  float* xreg = colT + BM * LDW2;         // [KC][RSZ]
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int b = blockIdx.x / ex.groups_per_image;
+  const int grp = blockIdx.x - b * ex.groups_per_image;
+  const int cs0 = blockIdx.y * WSC;       // first input channel of this slice
+  const int co0 = blockIdx.z * SLAB;
+  const int HWo = a.Ho * a.Wo, HW = a.H * a.W;
+  const int Ktot = a.Cin * TAPS;
+  const int tiles = HWo / BM;
+  const float* gob = a.go + (long long)b * a.Cout * HWo;
+  const float* xb = a.x + (long long)b * a.Cin * HW;
+
+  f32x4 acc[WCH][MT][3];
+#pragma unroll
+  for (int h = 0; h < WCH; ++h)
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) acc[h][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int e = tid; e < BM * (LDW2 - KK); e += 256) {          // zero the pad columns once
+    const int pp = e / (LDW2 - KK);
+    colT[pp * LDW2 + KK + (e - pp * (LDW2 - KK))] = 0.f;
+  }
+
+  const int t_begin = grp * ex.T, t_end = min(tiles, t_begin + ex.T);
+  for (int tile = t_begin; tile < t_end; ++tile) {
+    const int p0 = tile * BM, p = p0 + lane;
+    const int ty = p0 / a.W, tx0 = p0 - ty * a.W;
+    const int ry0 = ty - RR, rx0 = tx0 - RR;
+    Recipe r;
+    build_recipe(a, b, p, true, r);
+    int rbase[TAPS];
+    {
+      const float* off = a.offset + (long long)b * a.offset_bstride;
+#pragma unroll
+      for (int t = 0; t < TAPS; ++t) {
+        const int ky = t / 3, kx = t - ky * 3;
+        const float py = (float)(ty * a.stride - a.pad + ky * a.dil) + off[(long long)(2 * t) * HWo + p];
+        const float px = (float)((tx0 + lane) * a.stride - a.pad + kx * a.dil) +
+                         off[(long long)(2 * t + 1) * HWo + p];
+        const bool inside = py > -1.f && px > -1.f && py < (float)a.H && px < (float)a.W;
+        const int y0 = (int)floorf(py), x0 = (int)floorf(px);
+        const int ry = y0 - ry0, rx = x0 - rx0;
+        rbase[t] = (inside && ry >= 0 && ry + 1 < RH && rx >= 0 && rx + 1 < RW) ? ry * RWP + rx
+                   : (inside ? -1 : -2);
+      }
+    }
+    float xr[RPT];
+    auto issue = [&](int c0) {
+#pragma unroll
+      for (int i = 0; i < RPT; ++i) {
+        const int e = tid + i * 256;
+        const int cl = e / RSZ, rem = e - cl * RSZ;
+        const int ry = rem / RWP, rx = rem - ry * RWP;
+        const int gy_ = ry0 + ry, gx_ = rx0 + rx, c = c0 + cl;
+        const bool ok = e < KC * RSZ && rx < RW && c < a.Cin && gy_ >= 0 && gy_ < a.H && gx_ >= 0 && gx_ < a.W;
+        xr[i] = ok ? xb[(long long)c * HW + gy_ * a.W + gx_] : 0.f;
+      }
+    };
+    issue(cs0);
+    __syncthreads();                       // previous tile's MFMA reads of goT/colT are done
+    for (int idx = tid; idx < SLAB * BM; idx += 256) {
+      const int co = idx / BM, pp = idx - co * BM;
+      goT[pp * LDS_ + co] = (co0 + co < a.Cout) ? gob[(long long)(co0 + co) * HWo + p0 + pp] : 0.f;
+    }
+#pragma unroll
+    for (int h = 0; h < WCH; ++h) {
+      const int c0 = cs0 + h * KC;
+      __syncthreads();                     // colT / xreg free again
+#pragma unroll
+      for (int i = 0; i < RPT; ++i) {
+        const int e = tid + i * 256;
+        if (e < KC * RSZ) xreg[e] = xr[i];
+      }
+      __syncthreads();
+      if (h + 1 < WCH) issue(c0 + KC);     // next chunk's region loads fly during sampling + MFMA
+      // ---- sample: wave w handles channel c0 + w ----
+      {
+        const int c = c0 + wid;
+        const bool c_ok = c < a.Cin;
+        const float* xc = xb + (long long)(c_ok ? c : 0) * HW;
+        const float* xw = xreg + wid * RSZ;
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t) {
+          const int rb = rbase[t];
+          float val = 0.f;
+          if (rb != -2 && c_ok) {
+            float v00, v01, v10, v11;
+            if (rb >= 0) {
+              v00 = xw[rb]; v01 = xw[rb + 1]; v10 = xw[rb + RWP]; v11 = xw[rb + RWP + 1];
+            } else {
+              const unsigned vb = corner_bits(r, t);
+              const int dx = (r.step >> (2 * t)) & 1;
+              const int dy = ((r.step >> (2 * t + 1)) & 1) ? a.W : 0;
+              const float* q = xc + r.base[t];
+              v00 = (vb & 1u) ? q[0] : 0.f;
+              v01 = (vb & 2u) ? q[dx] : 0.f;
+              v10 = (vb & 4u) ? q[dy] : 0.f;
+              v11 = (vb & 8u) ? q[dy + dx] : 0.f;
+            }
+            const float ly = r.ly[t], lx = r.lx[t], hy = 1.f - ly, hx = 1.f - lx;
+            val = (hy * hx * v00 + hy * lx * v01 + ly * hx * v10 + ly * lx * v11) * r.m[t];
+          }
+          colT[lane * LDW2 + wid * TAPS + t] = val;
+        }
+      }
+      __syncthreads();
+      // ---- D[co][kk] += sum_px goT[px][co] * colT[px][kk]; wave w owns co rows [16*MT*w, 16*MT*(w+1)) ----
+#pragma unroll 8
+      for (int ks = 0; ks < BM / 4; ++ks) {
+        const int px = ks * 4 + (lane >> 4);
+        const float b0 = colT[px * LDW2 + (lane & 15)];
+        const float b1 = colT[px * LDW2 + 16 + (lane & 15)];
+        const float b2 = colT[px * LDW2 + 32 + (lane & 15)];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+          const float ai = goT[px * LDS_ + wid * (16 * MT) + i * 16 + (lane & 15)];
+          acc[h][i][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ai, b0, acc[h][i][0], 0, 0, 0);
+          acc[h][i][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ai, b1, acc[h][i][1], 0, 0, 0);
+          acc[h][i][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(ai, b2, acc[h][i][2], 0, 0, 0);
+        }
+      }
+    }
+  }
+  // ---- one atomic flush of the [128 co][WSC*9] tile ----
+#pragma unroll
+  for (int h = 0; h < WCH; ++h)
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const int kk = j * 16 + (lane & 15);
+        const int kg = (cs0 + h * KC) * TAPS + kk;
+        if (kk >= KK || kg >= Ktot) continue;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int co = co0 + wid * (16 * MT) + i * 16 + (lane >> 4) * 4 + q;
+          if (co < a.Cout) atomicAdd(&a.gw[(long long)co * Ktot + kg], acc[h][i][j][q]);
+        }
+      }
+}
+
+// grad_bias[co] += sum_{b,p} go[b][co][p]; grid = (Cout, segments of the B*HW range).
+constexpr int BIAS_SEG = 16384;
 __global__ __launch_bounds__(256) void dcn_bwd_bias_kernel(const float* __restrict__ go,
                                                            float* __restrict__ gb, int B, int Cout,
                                                            int HWo) {
   const int co = blockIdx.x;
-  double s = 0;
-  for (int b = 0; b < B; ++b) {
-    const float* q = go + ((long long)b * Cout + co) * HWo;
-    for (int i = threadIdx.x; i < HWo; i += 256) s += (double)q[i];
+  const long long total = (long long)B * HWo;
+  const long long s0 = (long long)blockIdx.y * BIAS_SEG;
+  const long long s1 = s0 + BIAS_SEG < total ? s0 + BIAS_SEG : total;
+  float s = 0.f;
+  for (long long i = s0 + threadIdx.x; i < s1; i += 256) {
+    const long long b = i / HWo, p = i - b * HWo;
+    s += go[(b * Cout + co) * HWo + p];
   }
-  s = cp_wave_sum_d(s);
-  __shared__ double red[4];
+  s = cp_wave_sum(s);
+  __shared__ float red[4];
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
-  if (threadIdx.x == 0) gb[co] += (float)(red[0] + red[1] + red[2] + red[3]);
+  if (threadIdx.x == 0) atomicAdd(&gb[co], red[0] + red[1] + red[2] + red[3]);
 }
 
 inline int out_extent(int in, int pad, int dil, int stride) {
@@ -672,12 +841,35 @@ extern "C" int cp_dcn_v2_backward(const cp_dcn_shape* s, const float* x, const f
     }
   }
   if (grad_weight) {
-    const size_t lds = (size_t)(BM * LDC + BM * LDK) * sizeof(float);
-    hipLaunchKernelGGL(dcn_bwd_weight_kernel, dim3(tiles, s->B, (s->Cout + COC - 1) / COC),
-                       dim3(256), lds, st, a);
+    const bool tiled_w = s->stride == 1 && Wo == s->W && Ho == s->H && (s->W % BM) == 0;
+    const int slab = s->Cout <= 64 ? 64 : COC;
+    const int slabs = (s->Cout + slab - 1) / slab;
+    if (tiled_w) {
+      const int slices = (s->Cin + WSC - 1) / WSC;
+      const long long blocks1 = (long long)tiles * s->B * slices * slabs;
+      int T = (int)(blocks1 / 2048);
+      if (T < 1) T = 1;
+      if (T > 16) T = 16;
+      if (T > tiles) T = tiles;
+      WTiledExtra ex;
+      ex.T = T;
+      ex.groups_per_image = (tiles + T - 1) / T;
+      const size_t lds = (size_t)(BM * (slab + 1) + BM * 49 + KC * RSZ) * sizeof(float);
+      const dim3 grid(ex.groups_per_image * s->B, slices, slabs);
+      if (slab == 64)
+        hipLaunchKernelGGL((dcn_bwd_weight_tiled_kernel<64, 2>), grid, dim3(256), lds, st, a, ex);
+      else
+        hipLaunchKernelGGL((dcn_bwd_weight_tiled_kernel<128, 1>), grid, dim3(256), lds, st, a, ex);
+    } else {
+      const size_t lds = (size_t)(BM * LDC + BM * LDK) * sizeof(float);
+      hipLaunchKernelGGL(dcn_bwd_weight_kernel, dim3(tiles, s->B, (s->Cout + COC - 1) / COC),
+                         dim3(256), lds, st, a);
+    }
   }
-  if (grad_bias)
-    hipLaunchKernelGGL(dcn_bwd_bias_kernel, dim3(s->Cout), dim3(256), 0, st, grad_out, grad_bias,
-                       s->B, s->Cout, Ho * Wo);
+  if (grad_bias) {
+    const long long total = (long long)s->B * Ho * Wo;
+    hipLaunchKernelGGL(dcn_bwd_bias_kernel, dim3(s->Cout, (unsigned)((total + BIAS_SEG - 1) / BIAS_SEG)),
+                       dim3(256), 0, st, grad_out, grad_bias, s->B, s->Cout, Ho * Wo);
+  }
   return cp_launch_status();
 }
