@@ -306,6 +306,11 @@ DCN_SHAPES = [
     (1, 256, 256, 12, 20),
     (2, 24, 40, 13, 19),        # ragged: channels not multiples of the tile, odd extent
     (1, 8, 300, 9, 7),          # Cout > 256 -> two N tiles
+    # W % 64 == 0 -> direct-operand kernel (LDS input region), all three N tiles, ragged Cin
+    (1, 24, 40, 5, 128),
+    (2, 130, 200, 4, 64),
+    (1, 64, 128, 6, 192),
+    (1, 16, 64, 40, 64),
 ]
 
 
