@@ -47,8 +47,24 @@ def _use_folded(m):
     return getattr(m, "_folded", None) is not None and not m.training and not torch.is_grad_enabled()
 
 
-def _conv_folded(x, conv, wb):
-    return F.conv2d(x, wb[0], wb[1], conv.stride, conv.padding, conv.dilation, conv.groups)
+def _conv_folded(x, conv, wb, relu=False, residual=None):
+    """conv with folded-BN weights, then ONE fused in-place pass: + bias (+ residual) (+ ReLU)."""
+    if not x.is_cuda:
+        y = F.conv2d(x, wb[0], wb[1], conv.stride, conv.padding, conv.dilation, conv.groups)
+        if residual is not None:
+            y = y + residual
+        return F.relu_(y) if relu else y
+    y = F.conv2d(x, wb[0], None, conv.stride, conv.padding, conv.dilation, conv.groups)
+    B, C, H, W = y.shape
+    if not y.is_contiguous() or (H * W) % 4 != 0 or (residual is not None and not residual.is_contiguous()):
+        y = y + wb[1].view(1, -1, 1, 1)
+        if residual is not None:
+            y = y + residual
+        return F.relu_(y) if relu else y
+    rc = _C.lib().cp_bias_act_inplace(_C.ptr(y), _C.ptr(wb[1]), _C.ptr(residual), B, C, H * W,
+                                      1 if relu else 0, _C.stream())
+    _C.check(rc, "cp_bias_act_inplace")
+    return y
 
 
 class BasicBlock(nn.Module):
@@ -67,10 +83,8 @@ class BasicBlock(nn.Module):
     def forward(self, x, residual=None):
         skip = x if residual is None else residual
         if _use_folded(self):
-            y = F.relu_(_conv_folded(x, self.conv1, self._folded[0]))
-            y = _conv_folded(y, self.conv2, self._folded[1])
-            y += skip
-            return F.relu_(y)
+            y = _conv_folded(x, self.conv1, self._folded[0], relu=True)
+            return _conv_folded(y, self.conv2, self._folded[1], relu=True, residual=skip)
         y = self.relu(self.bn1(self.conv1(x)))
         y = self.bn2(self.conv2(y))
         y += skip
@@ -90,10 +104,8 @@ class Root(nn.Module):
 
     def forward(self, *xs):
         if _use_folded(self):
-            y = _conv_folded(torch.cat(xs, 1), self.conv, self._folded)
-            if self.residual:
-                y += xs[0]
-            return F.relu_(y)
+            return _conv_folded(torch.cat(xs, 1), self.conv, self._folded, relu=True,
+                                residual=xs[0] if self.residual else None)
         y = self.bn(self.conv(torch.cat(xs, 1)))
         if self.residual:
             y += xs[0]
@@ -183,7 +195,7 @@ class DLA(nn.Module):
         pyramid = []
         if _use_folded(self):
             for seq, wb in zip((self.base_layer, self.level0, self.level1), self._folded):
-                x = F.relu_(_conv_folded(x, seq[0], wb))
+                x = _conv_folded(x, seq[0], wb, relu=True)
                 if seq is not self.base_layer:
                     pyramid.append(x)
             first_tree = 2
@@ -346,25 +358,49 @@ class DLASeg(nn.Module):
             self.__setattr__(head, fc)
 
     def prepare_inference(self):
-        """Fold every BatchNorm into its convolution / DCN epilogue (call after loading weights,
-        in eval mode).  Undone by train()."""
+        """Fold every BatchNorm into its convolution / DCN epilogue and concatenate the heads'
+        first 3x3 convolutions into one (call after loading weights, in eval mode).  Undone by
+        train()."""
         self.eval()
         for m in self.modules():
             if hasattr(m, "fold"):
                 m.fold()
+        self._heads_cat = None
+        fcs = [getattr(self, h) for h in self.heads]
+        if all(isinstance(fc, nn.Sequential) and len(fc) == 3 for fc in fcs):
+            with torch.no_grad():
+                self._heads_cat = (torch.cat([fc[0].weight for fc in fcs], 0).contiguous(),
+                                   torch.cat([fc[0].bias for fc in fcs], 0).contiguous())
         return self
+
+    def _heads_fast(self, feat):
+        """All heads' conv3x3 as ONE convolution (they share the input), one fused bias+ReLU
+        pass, then the per-head 1x1 convolutions on channel slices."""
+        w, b = self._heads_cat
+        y = _conv_folded(feat, getattr(self, next(iter(self.heads)))[0], (w, b), relu=True)
+        out, c0 = {}, 0
+        for h in self.heads:
+            fc = getattr(self, h)
+            hc = fc[0].out_channels
+            out[h] = fc[2](y[:, c0:c0 + hc])
+            c0 += hc
+        return out
 
     def train(self, mode=True):
         if mode:
             for m in self.modules():
                 if hasattr(m, "_folded"):
                     m._folded = None
+            self._heads_cat = None
         return super().train(mode)
 
     def forward(self, x):
         x = self.dla_up(self.base(x))
         y = [x[i].clone() for i in range(self.last_level - self.first_level)]
         self.ida_up(y, 0, len(y))
+        if getattr(self, "_heads_cat", None) is not None and not self.training \
+                and not torch.is_grad_enabled() and y[-1].is_cuda:
+            return [self._heads_fast(y[-1])]
         return [{head: getattr(self, head)(y[-1]) for head in self.heads}]
 
 

@@ -126,6 +126,11 @@ int cp_dcn_v2_backward(const cp_dcn_shape* s, const float* x, const float* offse
 int cp_depthwise_up_forward(const float* x, const float* weight, const float* skip, float* out,
                             int32_t B, int32_t C, int32_t H, int32_t W, int32_t f, void* stream);
 
+/* y <- act(y + bias[c] + residual) in place (fp32 NCHW, HW = H*W): the epilogue of a library
+ * convolution whose BatchNorm was folded (inference).  bias / residual may be NULL. */
+int cp_bias_act_inplace(float* y, const float* bias, const float* residual, int32_t B, int32_t C,
+                        int64_t HW, int32_t relu, void* stream);
+
 /* ----------------------------------------------------------------- decode --
  * heat [B,C,H,W] (already activated), polys [B,2N,H,W], depth [B,1,H,W],
  * reg [B,2,H,W] or NULL (then +0.5).  K <= 256.

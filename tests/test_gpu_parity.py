@@ -478,6 +478,21 @@ def test_depthwise_up_add_vs_conv_transpose(f, C, H, W):
     np.testing.assert_allclose(out.numpy(), ref.numpy(), rtol=1e-5, atol=1e-6)
 
 
+def test_folded_conv_epilogue_matches_bn_relu():
+    """BasicBlock in eval mode: folded conv + fused bias/residual/ReLU pass == conv, BN, add, ReLU."""
+    from centerpoly_amd.models.networks.pose_dla_dcn import BasicBlock
+    blk = BasicBlock(16, 16).to(DEV).eval()
+    sd = {k: T(v) for k, v in cases.fill_weights({k: tuple(v.shape) for k, v in blk.state_dict().items()}).items()}
+    blk.load_state_dict(sd)
+    x = g(synth.normal("fold/x", (2, 16, 12, 20)))
+    res = g(synth.normal("fold/r", (2, 16, 12, 20)))
+    with torch.no_grad():
+        ref = blk(x, res)
+        blk.fold()
+        out = blk(x, res)
+    np.testing.assert_allclose(out.cpu().numpy(), ref.cpu().numpy(), rtol=1e-4, atol=1e-5)
+
+
 # ------------------------------------------------------------------- nets ---
 
 def _load_by_name(model, gold):
@@ -486,11 +501,15 @@ def _load_by_name(model, gold):
     return model.to(DEV).eval()
 
 
-def test_dla34_forward_vs_reference_golden(golden):
-    """Reference DLASeg wiring (with the oracle's DCN in the plugin slot) vs the HIP path."""
+@pytest.mark.parametrize("fused", [False, True], ids=["plain", "prepare_inference"])
+def test_dla34_forward_vs_reference_golden(fused, golden):
+    """Reference DLASeg wiring (with the oracle's DCN in the plugin slot) vs the HIP path, with and
+    without the inference fusions (folded BN, fused epilogues, concatenated heads)."""
     from centerpoly_amd.models.model import create_model
     gold = golden("net_dla34")
     m = _load_by_name(create_model("dla_34", dict(cases.HEADS), 256), gold)
+    if fused:
+        m.prepare_inference()
     with torch.no_grad():
         out = m(g(cases.net_input("dla")))[0]
     for h in dict(cases.HEADS):
