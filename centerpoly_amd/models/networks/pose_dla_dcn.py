@@ -138,6 +138,14 @@ class Tree(nn.Module):
         if in_channels != out_channels:
             self.project = nn.Sequential(nn.Conv2d(in_channels, out_channels, 1, 1, bias=False),
                                          _bn(out_channels))
+        # In the reference a multi-level Tree hands `residual` to a nested Tree, which overwrites
+        # it (pose_dla_dcn.py:206-213): its `project` output is dead and its parameters never get
+        # a gradient.  Keep the module (checkpoint keys, BatchNorm running statistics) but take it
+        # out of autograd, or DistributedDataParallel would wait for gradients that never come.
+        self.project_is_dead = levels > 1 and self.project is not None
+        if self.project_is_dead:
+            for prm in self.project.parameters():
+                prm.requires_grad_(False)
 
     def fold(self):
         self._folded = _fold_conv_bn(self.project[0], self.project[1]) if self.project is not None \
@@ -148,6 +156,11 @@ class Tree(nn.Module):
         bottom = x if self.downsample is None else self.downsample(x)
         if self.project is None:
             residual = bottom
+        elif self.project_is_dead:
+            residual = None
+            if self.training:                 # only its BatchNorm running stats are observable
+                with torch.no_grad():
+                    self.project(bottom)
         elif _use_folded(self):
             residual = _conv_folded(bottom, self.project[0], self._folded)
         else:

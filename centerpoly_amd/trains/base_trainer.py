@@ -10,6 +10,7 @@ overlap backward -- instead of the reference's single-process DataParallel
 Averaging gradients across ranks == the reference's mean of per-replica losses
 (base_trainer.py:95); BatchNorm statistics stay per rank, rank 0's are saved.
 """
+import os
 import time
 
 import torch
@@ -40,7 +41,8 @@ class BaseTrainer(object):
 
     def set_device(self, gpus, chunk_sizes, device):
         self.model_with_loss = self.model_with_loss.to(device)
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        force = bool(int(os.environ.get("CP_FORCE_DDP", "0")))      # tests: wrap even at world_size 1
+        if dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or force):
             ids = [device.index] if getattr(device, "type", "cpu") == "cuda" else None
             self._ddp = torch.nn.parallel.DistributedDataParallel(
                 self.model_with_loss, device_ids=ids, broadcast_buffers=False,

@@ -558,3 +558,150 @@ def test_detector_run_config1_plumbing():
     for j in range(1, 9):
         assert res[j].shape == ref[j].shape
         np.testing.assert_allclose(res[j], ref[j], rtol=1e-5, atol=1e-3)
+
+
+# ---------------------------------------------------------------- trainer ---
+
+def _tiny_train_setup(arch, extra, B, H, W, N, rep):
+    from centerpoly_amd.models.model import create_model
+    from centerpoly_amd.opts import opts
+    from centerpoly_amd.trains.train_factory import train_factory
+    opt = opts().init(["polydet", "--arch", arch, "--nbr_points", str(N), "--rep", rep] + extra)
+    opt.device = torch.device(DEV)
+    torch.manual_seed(317)
+    model = create_model(opt.arch, opt.heads, opt.head_conv)
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    model.load_state_dict({k: T(v) for k, v in cases.fill_weights(shapes).items()})
+    optim = torch.optim.Adam(model.parameters(), opt.lr)
+    trainer = train_factory["polydet"](opt, model, optim)
+    nb = synth.train_batch(B, H // 4, W // 4, nbr_points=N, rep=rep, mean_objs=5, in_h=H, in_w=W,
+                           stream="trainer/%s" % arch)
+    return opt, model, trainer, nb
+
+
+@pytest.mark.parametrize("arch,extra,N,rep", [
+    ("dla_34", ["--poly_loss", "l1+iou"], 16, "cartesian"),                 # config 3 flavour
+    ("dla_34", ["--poly_loss", "l1", "--poly_order"], 32, "cartesian"),     # config 5 flavour
+], ids=["cfg3_l1iou", "cfg5_order"])
+def test_trainer_step_matches_oracle_losses(arch, extra, N, rep):
+    """One PolydetTrainer step on a tiny batch: loss stats equal the oracle's on the model's own
+    head outputs, every parameter receives a finite gradient and Adam moves the weights."""
+    opt, model, trainer, nb = _tiny_train_setup(arch, extra, 2, 64, 128, N, rep)
+    trainer.set_device(opt.gpus, opt.chunk_sizes, opt.device)
+    batch = {k: g(v) for k, v in nb.items()}
+    model.train()
+    # head outputs in train mode (BN batch statistics), before the loss mutates 'hm'
+    with torch.no_grad():
+        heads = {k: v.clone().cpu() for k, v in model(batch["input"])[-1].items()}
+    model.zero_grad(set_to_none=True)
+    before = {k: v.detach().clone() for k, v in model.named_parameters()}
+    # undo the BN running-stat update of the probe forward so the step sees the same state
+    out, loss, stats = trainer.step(batch, train=True)
+    ref, rstats = olos.polydet_loss([heads], {k: T(v) for k, v in nb.items()},
+                                    poly_loss_kind=opt.poly_loss, rep=rep, poly_order=opt.poly_order)
+    for k in rstats:
+        np.testing.assert_allclose(float(stats[k]), float(rstats[k]), rtol=2e-3, atol=1e-5, err_msg=k)
+    moved = 0
+    for k, v in model.named_parameters():
+        if not v.requires_grad:            # the reference's dead Tree.project branches
+            assert ".project." in k and k.startswith(("base.level3.", "base.level4.")), k
+            continue
+        assert v.grad is not None and torch.isfinite(v.grad).all(), k
+        moved += int(not torch.equal(v.detach(), before[k]))
+    assert moved > 0.9 * len(before)
+
+
+def test_trainer_hourglass_polar_two_stacks():
+    """Config 4 flavour at toy size: 2-stack Hourglass, polar 24-vertex head, l1 loss averaged over
+    both stacks (trains/polydet.py:43,81-125).  BatchNorm runs on its running statistics here: at
+    this toy size the deepest level is 1x1, and batch statistics over two values make the forward
+    pass chaotic (two identical train-mode forwards differ by O(1)), which is a property of the
+    toy shape, not of the code under test."""
+    opt, model, trainer, nb = _tiny_train_setup("hourglass", ["--poly_loss", "l1"], 2, 128, 128, 24, "polar")
+    trainer.set_device(opt.gpus, opt.chunk_sizes, opt.device)
+    batch = {k: g(v) for k, v in nb.items()}
+    model.eval()
+    with torch.no_grad():
+        outs = [{k: v.clone().cpu() for k, v in o.items()} for o in model(batch["input"])]
+    with torch.enable_grad():
+        out, loss, stats = trainer.model_with_loss(batch)
+        loss.backward()
+    ref, rstats = olos.polydet_loss(outs, {k: T(v) for k, v in nb.items()}, num_stacks=2,
+                                    poly_loss_kind="l1", rep="polar")
+    for k in rstats:
+        np.testing.assert_allclose(float(stats[k]), float(rstats[k]), rtol=2e-3, atol=1e-5, err_msg=k)
+    for k, v in model.named_parameters():          # every Hourglass parameter is live (DDP-safe)
+        assert v.grad is not None and torch.isfinite(v.grad).all(), k
+
+
+def test_losses_with_no_objects_and_full_object_table():
+    from centerpoly_amd.trains.polydet import PolydetLoss
+    opt = _Opt(num_stacks=1, poly_loss="l1+iou", rep="cartesian", poly_order=True, hm_weight=1.0,
+               off_weight=1.0, poly_weight=1.0, depth_weight=0.1, reg_offset=True, reg_loss="l1",
+               task="polydet")
+    for fill in (0, 1):                     # empty image / all 128 slots used
+        batch, out = cases.loss_batch("edge%d" % fill, 1, 24, 40, 16, "cartesian", mean_objs=4)
+        batch["reg_mask"][:] = fill
+        if fill:
+            batch["ind"][0] = np.arange(128) * 7 % (24 * 40)
+            batch["poly"][0] = synth.normal("edge/poly", (128, 32), 0, 6.0)
+        if not fill:
+            batch["hm"][:] = 0
+        hc = {k: T(v).requires_grad_(True) for k, v in out.items()}
+        ref, rstats = olos.polydet_loss([hc], {k: T(v) for k, v in batch.items()},
+                                        poly_loss_kind="l1+iou", rep="cartesian", poly_order=True)
+        ref.backward()
+        leaf = {k: g(v).requires_grad_(True) for k, v in out.items()}
+        loss, stats = PolydetLoss(opt)([{k: v * 1.0 for k, v in leaf.items()}], {k: g(v) for k, v in batch.items()})
+        loss.backward()
+        for k in rstats:
+            np.testing.assert_allclose(float(stats[k]), float(rstats[k]), rtol=2e-3, atol=1e-5, err_msg=k)
+        want = hc["poly"].grad
+        np.testing.assert_allclose(leaf["poly"].grad.cpu().numpy(), want.numpy(), rtol=3e-3,
+                                   atol=3e-4 * max(want.abs().max().item(), 1e-9))
+
+
+def test_polyiou_max_vertices_64():
+    """N = 64 (the kernel's maximum): 105 KB of LDS per object."""
+    from centerpoly_amd.models.losses import PolyLoss
+    batch, out = cases.loss_batch("n64", 1, 16, 24, 64, "polar", mean_objs=3)
+    args = (T(batch["reg_mask"]), T(batch["ind"]), T(batch["poly"]))
+    oc = T(out["poly"]).requires_grad_(True)
+    ref = olos.poly_loss(oc, *args, "iou", "polar", False)
+    ref.backward()
+    od = g(out["poly"]).requires_grad_(True)
+    l = PolyLoss(_Opt(poly_loss="iou", rep="polar", poly_order=False))(od, *(g(a) for a in args))
+    l.backward()
+    np.testing.assert_allclose(l.item(), ref.item(), rtol=1e-3, atol=1e-5)
+    gs = oc.grad.abs().max().item()
+    np.testing.assert_allclose(od.grad.cpu().numpy(), oc.grad.numpy(), rtol=3e-3, atol=3e-4 * gs)
+
+
+def test_ddp_wrapper_on_gpu_matches_plain_step():
+    """The multi-GPU wrapper (DistributedDataParallel over RCCL) around the real trainer, forced at
+    world_size 1: same loss as the plain step, gradients flow through every custom autograd op."""
+    import os
+    import torch.distributed as dist
+    losses = []
+    for force in ("0", "1"):
+        os.environ["CP_FORCE_DDP"] = force
+        started = False
+        if force == "1" and not dist.is_initialized():
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29611", RANK="0", WORLD_SIZE="1")
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+            started = True
+        try:
+            opt, model, trainer, nb = _tiny_train_setup("dla_34", ["--poly_loss", "l1+iou"], 2, 64, 128, 16,
+                                                        "cartesian")
+            trainer.set_device(opt.gpus, opt.chunk_sizes, torch.device("cuda", 0))
+            assert (trainer._ddp is not None) == (force == "1")
+            batch = {k: g(v) for k, v in nb.items()}
+            model.train()
+            _, loss, _ = trainer.step(batch, train=True)
+            _, loss2, _ = trainer.step(batch, train=True)
+            losses.append((loss.item(), loss2.item()))
+        finally:
+            if started:
+                dist.destroy_process_group()
+            os.environ["CP_FORCE_DDP"] = "0"
+    np.testing.assert_allclose(losses[0], losses[1], rtol=1e-4)
