@@ -261,6 +261,13 @@ __global__ __launch_bounds__(256) void dcn_bwd_data_kernel(DcnBwdArgs a) {
   }
 }
 
+// Exact round-to-nearest float -> int64 for |x| < 2^51 in 3 VALU instructions (cvt to double,
+// add 2^52 + 2^51, integer-subtract the constant's bit pattern); __float2ll_rn is 12.
+__device__ __forceinline__ unsigned long long fx_from_float(float x) {
+  const double d = (double)x + 6755399441055744.0;
+  return (unsigned long long)(__double_as_longlong(d) - 0x4338000000000000ll);
+}
+
 // ------------------------------------------------------- tiled data kernel ---
 constexpr int RR = 3;                    // region halo (pixels)
 constexpr int RH = 2 * RR + 2;           // 8 rows
@@ -440,10 +447,10 @@ __global__ __launch_bounds__(256, WPS) void dcn_bwd_data_tiled_kernel(DcnBwdArgs
         if (gxb) {
           if (rb >= 0) {                   // cells outside the image are dropped at the flush
             const float gs = gcm * fx_scale;
-            atomicAdd(&gw_[rb], (unsigned long long)__float2ll_rn(gs * (hy * hx)));
-            atomicAdd(&gw_[rb + 1], (unsigned long long)__float2ll_rn(gs * (hy * lx)));
-            atomicAdd(&gw_[rb + RWP], (unsigned long long)__float2ll_rn(gs * (ly * hx)));
-            atomicAdd(&gw_[rb + RWP + 1], (unsigned long long)__float2ll_rn(gs * (ly * lx)));
+            atomicAdd(&gw_[rb], fx_from_float(gs * (hy * hx)));
+            atomicAdd(&gw_[rb + 1], fx_from_float(gs * (hy * lx)));
+            atomicAdd(&gw_[rb + RWP], fx_from_float(gs * (ly * hx)));
+            atomicAdd(&gw_[rb + RWP + 1], fx_from_float(gs * (ly * lx)));
           } else if (vb) {
             float* q = gxb + (long long)c * HW + r.base[t];
             if (vb & 1u) atomicAdd(q, gcm * hy * hx);

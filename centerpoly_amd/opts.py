@@ -51,6 +51,10 @@ class opts(object):
         p.add_argument("--trainval", action="store_true")
         p.add_argument("--clip", action="store_true")
         p.add_argument("--clip_value", type=float, default=1.0)
+        p.add_argument("--root_dir", default="../",
+                       help="where exp/<dataset>/<task>/<exp_id> is created (reference: hard-coded ../)")
+        p.add_argument("--synthetic_samples", type=int, default=64,
+                       help="items per epoch of the synthetic dataset")
         p.add_argument("--bucket_cap_mb", type=int, default=32,
                        help="gradient all-reduce bucket size (RCCL over xGMI)")
         # test
@@ -104,7 +108,7 @@ class opts(object):
             if i < rest % (len(opt.gpus) - 1):
                 chunk += 1
             opt.chunk_sizes.append(chunk)
-        opt.root_dir = os.path.join("../")
+        opt.root_dir = os.path.join(opt.root_dir)
         opt.data_dir = opt.root_dir
         opt.exp_dir = os.path.join(opt.root_dir, "exp", opt.dataset, opt.task)
         opt.save_dir = os.path.join(opt.exp_dir, opt.exp_id)
