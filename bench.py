@@ -16,6 +16,7 @@ Launch for N > 1:  python -m torch.distributed.run --nnodes=1 --nproc-per-node N
                    --master-addr 127.0.0.1 --master-port P bench.py --gpus N --steps K --warmup W
 """
 import argparse
+import contextlib
 import json
 import os
 import sys
@@ -158,8 +159,9 @@ def train_leg(args, dev, world, rank, steps, warmup):
     from centerpoly_amd import synth
     from centerpoly_amd.opts import opts
     from centerpoly_amd.trains.train_factory import train_factory
-    opt = opts().init(["polydet", "--arch", "dla_34", "--poly_loss", "l1+iou", "--nbr_points", "16",
-                       "--batch_size", str(args.train_batch * world)])
+    with contextlib.redirect_stdout(sys.stderr):          # stdout carries the JSON line only
+        opt = opts().init(["polydet", "--arch", "dla_34", "--poly_loss", "l1+iou", "--nbr_points", "16",
+                           "--batch_size", str(args.train_batch * world)])
     opt.device = dev
     model, _ = build_model(dev, train=True)
     optimizer = torch.optim.Adam(model.parameters(), opt.lr)
@@ -216,7 +218,7 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=dev)
     mode = args.mode if args.mode != "auto" else ("infer" if world == 1 else "train")
-    torch.backends.cudnn.benchmark = False
+    torch.backends.cudnn.benchmark = os.environ.get("CP_MIOPEN_BENCHMARK", "0") == "1"
     line = {"n_gpus": world, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic (counter-hash inputs, name-hashed random-init weights)"}
