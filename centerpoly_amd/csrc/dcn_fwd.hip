@@ -58,6 +58,7 @@ struct DcnFwdArgs {
 
 template <int BN, int KC, int WPS>
 __global__ __launch_bounds__(256, WPS) void dcn_fwd_kernel(DcnFwdArgs a) {
+  static_assert(sizeof(int) == 4, "");
   constexpr int KK = KC * TAPS;          // k extent of one chunk
   constexpr int LD = KK + 1;             // odd row stride (dwords)
   constexpr int NT = BN / 32;            // 16-wide n tiles per wave
@@ -78,11 +79,13 @@ __global__ __launch_bounds__(256, WPS) void dcn_fwd_kernel(DcnFwdArgs a) {
   const bool p_ok = p < HWo;
 
   // ---- per-pixel sampling recipes, kept in registers ----
-  // cw[t][0..3]: corner weights x mask x validity; cbase[t]: clamped top-left index;
-  // bit 2t of cstep: right neighbour is +1 (else same column), bit 2t+1: lower is +W.
+  // cw[t][0..3]: corner weights x mask x validity; coff[t][0..3]: BYTE offsets of the four
+  // (clamped) corners inside one channel plane.  Gathers are raw buffer loads: wave-uniform
+  // resource descriptor (SGPRs) + this 32-bit per-lane offset + the channel's plane offset in
+  // the scalar soffset operand -- no per-gather 64-bit VALU address arithmetic (PMC showed the
+  // flat-address form issue-bound: 6.7 VALU per MFMA), and out-of-range reads return 0.
   float cw[TAPS][4];
-  int cbase[TAPS];
-  unsigned cstep = 0;
+  unsigned coff[TAPS][4];
   {
     const int ho = p_ok ? p / a.Wo : 0;
     const int wo = p_ok ? p - ho * a.Wo : 0;
@@ -91,9 +94,9 @@ __global__ __launch_bounds__(256, WPS) void dcn_fwd_kernel(DcnFwdArgs a) {
     float oy[TAPS], ox[TAPS], mk[TAPS];
 #pragma unroll
     for (int t = 0; t < TAPS; ++t) {
-      oy[t] = p_ok ? off[(long long)(2 * t) * HWo + p] : 0.f;
-      ox[t] = p_ok ? off[(long long)(2 * t + 1) * HWo + p] : 0.f;
-      mk[t] = p_ok ? msk[(long long)t * HWo + p] : 0.f;
+      oy[t] = (p_ok && !CP_ABL(16)) ? off[(long long)(2 * t) * HWo + p] : 0.f;
+      ox[t] = (p_ok && !CP_ABL(16)) ? off[(long long)(2 * t + 1) * HWo + p] : 0.f;
+      mk[t] = (p_ok && !CP_ABL(16)) ? msk[(long long)t * HWo + p] : 0.f;
     }
 #pragma unroll
     for (int t = 0; t < TAPS; ++t) {
@@ -109,16 +112,16 @@ __global__ __launch_bounds__(256, WPS) void dcn_fwd_kernel(DcnFwdArgs a) {
       const float hy = 1.f - ly, hx = 1.f - lx;
       const bool y0ok = y0 >= 0, y1ok = y0 + 1 <= a.H - 1;
       const bool x0ok = x0 >= 0, x1ok = x0 + 1 <= a.W - 1;
-      const int y0c = min(max(y0, 0), a.H - 1), x0c = min(max(x0, 0), a.W - 1);
+      const int y0c = min(max(y0, 0), a.H - 1), y1c = min(max(y0 + 1, 0), a.H - 1);
+      const int x0c = min(max(x0, 0), a.W - 1), x1c = min(max(x0 + 1, 0), a.W - 1);
       cw[t][0] = (inside && y0ok && x0ok) ? hy * hx * m : 0.f;
       cw[t][1] = (inside && y0ok && x1ok) ? hy * lx * m : 0.f;
       cw[t][2] = (inside && y1ok && x0ok) ? ly * hx * m : 0.f;
       cw[t][3] = (inside && y1ok && x1ok) ? ly * lx * m : 0.f;
-      cbase[t] = inside ? y0c * a.W + x0c : 0;
-      // a step is taken only when both ends are real pixels; otherwise the weight is 0
-      // and the read aliases a valid address
-      if (inside && x0ok && x1ok) cstep |= 1u << (2 * t);
-      if (inside && y0ok && y1ok) cstep |= 2u << (2 * t);
+      coff[t][0] = inside ? 4u * (unsigned)(y0c * a.W + x0c) : 0u;
+      coff[t][1] = inside ? 4u * (unsigned)(y0c * a.W + x1c) : 0u;
+      coff[t][2] = inside ? 4u * (unsigned)(y1c * a.W + x0c) : 0u;
+      coff[t][3] = inside ? 4u * (unsigned)(y1c * a.W + x1c) : 0u;
     }
   }
 
@@ -142,43 +145,52 @@ __global__ __launch_bounds__(256, WPS) void dcn_fwd_kernel(DcnFwdArgs a) {
   constexpr int WPT = (BN * KK + 255) / 256;     // weight elements per thread per chunk
   float g[CPW][TAPS][4];
   float wreg[WPT];
-  auto issue_loads = [&](int c0) {
+  // wave-uniform buffer descriptors (built from kernargs / blockIdx only)
+  const unsigned plane_bytes = (unsigned)HW * 4u;
+  const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(xb), 0, (int)((unsigned)a.Cin * plane_bytes), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.weight), 0, (int)((unsigned)a.Cout * (unsigned)Ktot * 4u), 0x00020000);
+  // per-thread weight element i: global byte offset (0xffffffff = out of range -> reads 0) and
+  // LDS slot, both fixed for the whole K loop; the chunk's k offset goes into soffset
+  unsigned woff[WPT];
+  int wlds[WPT];
 #pragma unroll
-    for (int i = 0; i < WPT; ++i) {
-      const int idx = tid + i * 256;
-      const int co = idx / KK;
-      const int kk = idx - co * KK;
-      const int kg = c0 * TAPS + kk;
-      float w = 0.f;
-      if (!CP_ABL(4) && idx < BN * KK && n0 + co < a.Cout && kg < c_end * TAPS)
-        w = a.weight[(long long)(n0 + co) * Ktot + kg];
-      wreg[i] = w;
-    }
+  for (int i = 0; i < WPT; ++i) {
+    const int idx = tid + i * 256;
+    const int co = idx / KK, kk = idx - co * KK;
+    const bool ok = idx < BN * KK && n0 + co < a.Cout;
+    woff[i] = ok ? ((unsigned)(n0 + co) * (unsigned)Ktot + (unsigned)kk) * 4u : 0xffffffffu;
+    wlds[i] = idx < BN * KK ? co * LD + kk : -1;
+  }
+  const int swid = __builtin_amdgcn_readfirstlane(wid);
+  auto issue_loads = [&](int c0) {
+    const unsigned wsoff = (unsigned)(c0 * TAPS) * 4u;
+#pragma unroll
+    for (int i = 0; i < WPT; ++i)
+      wreg[i] = CP_ABL(4) ? 0.f
+                          : __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_w, woff[i], wsoff, 0));
 #pragma unroll
     for (int cc = 0; cc < CPW; ++cc) {
-      const int c = c0 + wid * CPW + cc;
-      const float* xc = xb + (long long)(c < c_end ? c : c_begin) * HW;
+      const int c = c0 + swid * CPW + cc;
+      const unsigned xsoff = (unsigned)c * plane_bytes;      // c >= Cin reads out of range = 0
 #pragma unroll
       for (int t = 0; t < TAPS; ++t) {
         if (CP_ABL(1)) {
           g[cc][t][0] = g[cc][t][1] = g[cc][t][2] = g[cc][t][3] = 1.f;
           continue;
         }
-        const int dx = (cstep >> (2 * t)) & 1;
-        const int dy = ((cstep >> (2 * t + 1)) & 1) ? a.W : 0;
-        const float* q = xc + cbase[t];
-        g[cc][t][0] = q[0];
-        g[cc][t][1] = q[dx];
-        g[cc][t][2] = q[dy];
-        g[cc][t][3] = q[dy + dx];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          g[cc][t][k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_x, coff[t][k], xsoff, 0));
       }
     }
   };
   auto write_lds = [&](int c0) {
 #pragma unroll
     for (int cc = 0; cc < CPW; ++cc) {
-      const int cl = wid * CPW + cc;
-      const bool c_ok = c0 + cl < c_end;
+      const int cl = swid * CPW + cc;
+      const bool c_ok = c0 + cl < c_end;         // split-K: channels past this slice contribute 0
 #pragma unroll
       for (int t = 0; t < TAPS; ++t) {
         const float v = cw[t][0] * g[cc][t][0] + cw[t][1] * g[cc][t][1] +
@@ -188,13 +200,8 @@ __global__ __launch_bounds__(256, WPS) void dcn_fwd_kernel(DcnFwdArgs a) {
       }
     }
 #pragma unroll
-    for (int i = 0; i < WPT; ++i) {
-      const int idx = tid + i * 256;
-      if (idx < BN * KK) {
-        const int co = idx / KK;
-        wT[co * LD + (idx - co * KK)] = wreg[i];
-      }
-    }
+    for (int i = 0; i < WPT; ++i)
+      if (wlds[i] >= 0) wT[wlds[i]] = wreg[i];
   };
 
   if (c_begin < c_end) issue_loads(c_begin);
