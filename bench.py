@@ -51,12 +51,14 @@ def parse():
     p.add_argument("--width", type=int, default=2048)
     p.add_argument("--train_batch", type=int, default=4, help="images per GPU in training")
     p.add_argument("--train_steps", type=int, default=4, help="steps of the N=1 training point")
+    p.add_argument("--dcn_contraction", default="f32", choices=["f32", "bf16x3"],
+                   help="DCNv2 forward contraction at inference: exact fp32 MFMA or split-bf16 x3")
     p.add_argument("--no_cpu_baseline", action="store_true")
     p.add_argument("--no_train_point", action="store_true")
     return p.parse_args()
 
 
-def build_model(dev, train):
+def build_model(dev, train, dcn_contraction="f32"):
     from centerpoly_amd import synth
     from centerpoly_amd.models.model import create_model
     model = create_model("dla_34", dict(HEADS), 256)
@@ -70,7 +72,7 @@ def build_model(dev, train):
     model = model.to(dev)
     model.train(train)
     if not train and dev.type == "cuda":
-        model.prepare_inference()
+        model.prepare_inference(dcn_contraction=dcn_contraction)
     return model, sd
 
 
@@ -106,7 +108,7 @@ def timed(fn, steps, warmup, world, tag=""):
 def infer_leg(args, dev, world):
     from centerpoly_amd import _C, synth
     from centerpoly_amd.models.decode import polydet_decode
-    model, _ = build_model(dev, train=False)
+    model, _ = build_model(dev, train=False, dcn_contraction=args.dcn_contraction)
     x = torch.from_numpy(synth.normal("bench/input", (1, 3, args.height, args.width))).to(dev)
 
     def step():

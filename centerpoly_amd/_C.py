@@ -15,6 +15,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libcenterpoly_hip.so")
 CP_OK = 0
 REP = {"cartesian": 0, "polar": 1, "polar_fixed": 2}
 L1_PLAIN, L1_POLAR, L1_POLAR_FIXED, L1_RELU20 = 0, 1, 2, 3
+DCN_CONTRACTION = {"f32": 0, "bf16x3": 1}
 
 
 class DcnShape(Structure):
@@ -39,7 +40,7 @@ _SIGNATURES = {
     "cp_build_arch": (c_char_p, []),
     "cp_dcn_v2_forward_workspace_bytes": (c_size_t, [POINTER(DcnShape)]),
     "cp_dcn_v2_forward": (c_int32, [POINTER(DcnShape), _P, _P, c_int64, _P, c_int64, c_int32, _P, _P,
-                                    _P, _P, c_int32, _P, _P, c_size_t, _P]),
+                                    _P, _P, c_int32, c_int32, _P, _P, c_size_t, _P]),
     "cp_dcn_v2_backward_workspace_bytes": (c_size_t, [POINTER(DcnShape)]),
     "cp_dcn_v2_backward": (c_int32, [POINTER(DcnShape), _P, _P, c_int64, _P, c_int64, c_int32, _P, _P,
                                      _P, _P, c_int64, _P, c_int64, _P, _P, _P, c_size_t, _P]),

@@ -20,9 +20,7 @@
 // LDS rows are padded to an odd dword count so both the lane=pixel writes and the
 // lane=(row, k) fragment reads are bank-conflict free.
 #include "cp_common.h"
-#ifdef CP_ABLATE
 #include <stdlib.h>
-#endif
 
 namespace {
 
@@ -151,7 +149,8 @@ __global__ __launch_bounds__(256, WPS) void dcn_fwd_kernel(DcnFwdArgs a) {
       const_cast<float*>(xb), 0, (int)((unsigned)a.Cin * plane_bytes), 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(a.weight), 0, (int)((unsigned)a.Cout * (unsigned)Ktot * 4u), 0x00020000);
-  // per-thread weight element i: global byte offset (0xffffffff = out of range -> reads 0) and
+  // per-thread weight element i: global byte offset (0xf0000000 + k offset never wraps and is
+  // always past num_records -> reads 0; tensors here are far below 3.7 GB) and
   // LDS slot, both fixed for the whole K loop; the chunk's k offset goes into soffset
   unsigned woff[WPT];
   int wlds[WPT];
@@ -160,20 +159,24 @@ __global__ __launch_bounds__(256, WPS) void dcn_fwd_kernel(DcnFwdArgs a) {
     const int idx = tid + i * 256;
     const int co = idx / KK, kk = idx - co * KK;
     const bool ok = idx < BN * KK && n0 + co < a.Cout;
-    woff[i] = ok ? ((unsigned)(n0 + co) * (unsigned)Ktot + (unsigned)kk) * 4u : 0xffffffffu;
+    woff[i] = ok ? ((unsigned)(n0 + co) * (unsigned)Ktot + (unsigned)kk) * 4u : 0xf0000000u;
     wlds[i] = idx < BN * KK ? co * LD + kk : -1;
   }
   const int swid = __builtin_amdgcn_readfirstlane(wid);
   auto issue_loads = [&](int c0) {
-    const unsigned wsoff = (unsigned)(c0 * TAPS) * 4u;
+    // NOTE: the scalar soffset operand is NOT range-checked by the hardware, only voffset is.
+    // The chunk's k offset therefore rides in voffset (past-the-end weights read 0), and the
+    // channel plane offset is clamped to the last plane (its samples are zeroed by c_ok).
+    const unsigned wk = (unsigned)(c0 * TAPS) * 4u;
 #pragma unroll
     for (int i = 0; i < WPT; ++i)
       wreg[i] = CP_ABL(4) ? 0.f
-                          : __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_w, woff[i], wsoff, 0));
+                          : __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                                          rs_w, woff[i] + wk, 0, 0));
 #pragma unroll
     for (int cc = 0; cc < CPW; ++cc) {
       const int c = c0 + swid * CPW + cc;
-      const unsigned xsoff = (unsigned)c * plane_bytes;      // c >= Cin reads out of range = 0
+      const unsigned xsoff = (unsigned)min(c, a.Cin - 1) * plane_bytes;
 #pragma unroll
       for (int t = 0; t < TAPS; ++t) {
         if (CP_ABL(1)) {
@@ -262,6 +265,430 @@ __global__ __launch_bounds__(256, WPS) void dcn_fwd_kernel(DcnFwdArgs a) {
   }
 }
 
+// ------------------------------------------------------- interleaved kernel ---
+// Same tiling as dcn_fwd_kernel, restructured so the matrix pipe never waits for a sampling
+// phase (PMC on the phase-separated kernel: MFMA busy 28 %, half of every wave's life spent
+// queued for the pipe because all waves reach their MFMA phase together).  The K loop body is
+// one k-step = one tap:
+//     MFMAs of chunk i, k-step t, from LDS buffer A            (matrix pipe)
+//     sample tap t of chunk i+1 from registers -> LDS buffer B  (VALU + ds_write, in the
+//     store weight element t of chunk i+1 -> LDS buffer B        shadow of the MFMAs)
+//     re-issue tap t's 4 gathers + weight element t for chunk i+2 into the SAME registers
+// so each gather has a full chunk time to land, nothing is double-buffered in registers, and
+// there is ONE barrier per chunk.  KC = 4 channels per chunk, wave w samples channel c0 + w.
+template <int BN, int WPS>
+__global__ __launch_bounds__(256, WPS) void dcn_fwd_pipe_kernel(DcnFwdArgs a) {
+  constexpr int KC = 4;
+  constexpr int KK = KC * TAPS;          // 36
+  constexpr int LD = KK + 1;             // 37
+  constexpr int NT = BN / 32;
+  constexpr int WPT = BN * KK / 256;     // weight elements per thread per chunk (9 / 18)
+  constexpr int WPK = WPT / TAPS;        // ... per k-step (1 / 2)
+  constexpr int BUF = (BM + BN) * LD;
+  static_assert(WPT % TAPS == 0, "weights spread evenly over the k-steps");
+  extern __shared__ float lds[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int b = blockIdx.z % a.B;
+  const int n0 = blockIdx.y * BN;
+  const int HWo = a.Ho * a.Wo, HW = a.H * a.W;
+  const int p = blockIdx.x * BM + lane;
+  const bool p_ok = p < HWo;
+
+  float cw[TAPS][4];
+  unsigned coff[TAPS][4];
+  {
+    const int ho = p_ok ? p / a.Wo : 0;
+    const int wo = p_ok ? p - ho * a.Wo : 0;
+    const float* off = a.offset + (long long)b * a.offset_bstride;
+    const float* msk = a.mask + (long long)b * a.mask_bstride;
+    float oy[TAPS], ox[TAPS], mk[TAPS];
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t) {
+      oy[t] = p_ok ? off[(long long)(2 * t) * HWo + p] : 0.f;
+      ox[t] = p_ok ? off[(long long)(2 * t + 1) * HWo + p] : 0.f;
+      mk[t] = p_ok ? msk[(long long)t * HWo + p] : 0.f;
+    }
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t) {
+      const int ky = t / 3, kx = t - ky * 3;
+      float m = mk[t];
+      if (a.mask_is_logit) m = 1.f / (1.f + __expf(-m));
+      const float py = (float)(ho * a.stride - a.pad + ky * a.dil) + oy[t];
+      const float px = (float)(wo * a.stride - a.pad + kx * a.dil) + ox[t];
+      const bool inside = p_ok && py > -1.f && px > -1.f && py < (float)a.H && px < (float)a.W;
+      const float fy = floorf(py), fx = floorf(px);
+      const int y0 = (int)fy, x0 = (int)fx;
+      const float ly = py - fy, lx = px - fx;
+      const float hy = 1.f - ly, hx = 1.f - lx;
+      const bool y0ok = y0 >= 0, y1ok = y0 + 1 <= a.H - 1;
+      const bool x0ok = x0 >= 0, x1ok = x0 + 1 <= a.W - 1;
+      const int y0c = min(max(y0, 0), a.H - 1), y1c = min(max(y0 + 1, 0), a.H - 1);
+      const int x0c = min(max(x0, 0), a.W - 1), x1c = min(max(x0 + 1, 0), a.W - 1);
+      cw[t][0] = (inside && y0ok && x0ok) ? hy * hx * m : 0.f;
+      cw[t][1] = (inside && y0ok && x1ok) ? hy * lx * m : 0.f;
+      cw[t][2] = (inside && y1ok && x0ok) ? ly * hx * m : 0.f;
+      cw[t][3] = (inside && y1ok && x1ok) ? ly * lx * m : 0.f;
+      coff[t][0] = inside ? 4u * (unsigned)(y0c * a.W + x0c) : 0u;
+      coff[t][1] = inside ? 4u * (unsigned)(y0c * a.W + x1c) : 0u;
+      coff[t][2] = inside ? 4u * (unsigned)(y1c * a.W + x0c) : 0u;
+      coff[t][3] = inside ? 4u * (unsigned)(y1c * a.W + x1c) : 0u;
+    }
+  }
+
+  f32x4 acc[2][NT];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int wm = wid >> 1, wn = wid & 1;
+  const int Ktot = a.Cin * TAPS;
+  const float* xb = a.x + (long long)b * a.Cin * HW;
+  const int ksl = (a.splitk > 1) ? (int)(blockIdx.z / a.B) : 0;
+  const int c_begin = ksl * a.c_per_split;
+  const int c_end = min(a.Cin, c_begin + a.c_per_split);
+
+  const unsigned plane_bytes = (unsigned)HW * 4u;
+  const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(xb), 0, (int)((unsigned)a.Cin * plane_bytes), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.weight), 0, (int)((unsigned)a.Cout * (unsigned)Ktot * 4u), 0x00020000);
+  unsigned woff[WPT];
+  int wlds[WPT];
+#pragma unroll
+  for (int i = 0; i < WPT; ++i) {
+    const int idx = tid + i * 256;
+    const int co = idx / KK, kk = idx - co * KK;
+    woff[i] = n0 + co < a.Cout ? ((unsigned)(n0 + co) * (unsigned)Ktot + (unsigned)kk) * 4u : 0xf0000000u;
+    wlds[i] = BM * LD + co * LD + kk;          // offset inside one buffer
+  }
+  const int swid = __builtin_amdgcn_readfirstlane(wid);
+  const int colw = lane * LD + swid * TAPS;    // this lane's column slot (+ tap) inside a buffer
+
+  float g[TAPS][4];
+  float wreg[WPT];
+  auto load_tap = [&](int c0, int t) {         // gathers of tap t (+ its share of the weights)
+    // soffset is not range-checked by the hardware (only voffset is): clamp the channel plane
+    // (foreign samples are zeroed in build_tap) and carry the chunk's k offset in voffset
+    const unsigned xsoff = (unsigned)min(c0 + swid, a.Cin - 1) * plane_bytes;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      g[t][k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_x, coff[t][k], xsoff, 0));
+    const unsigned wk = (unsigned)(c0 * TAPS) * 4u;
+#pragma unroll
+    for (int q = 0; q < WPK; ++q) {
+      wreg[t * WPK + q] = __builtin_bit_cast(
+          float, __builtin_amdgcn_raw_buffer_load_b32(rs_w, woff[t * WPK + q] + wk, 0, 0));
+    }
+  };
+  auto build_tap = [&](float* buf, int c0, int t) {   // tap t of chunk c0 -> LDS buffer `buf`
+    const float v = cw[t][0] * g[t][0] + cw[t][1] * g[t][1] + cw[t][2] * g[t][2] + cw[t][3] * g[t][3];
+    buf[colw + t] = (c0 + swid < c_end) ? v : 0.f;     // split-K: foreign channels contribute 0
+#pragma unroll
+    for (int q = 0; q < WPK; ++q) buf[wlds[t * WPK + q]] = wreg[t * WPK + q];
+  };
+
+  // prologue: chunk 0 -> buffer 0, chunk 1's loads in flight
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t) load_tap(c_begin, t);
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t) {
+    build_tap(lds, c_begin, t);
+    load_tap(c_begin + KC, t);
+  }
+  __syncthreads();
+
+  const int arow = (wm * 32 + (lane & 15)) * LD + (lane >> 4);
+  const int brow = BM * LD + (wn * (BN / 2) + (lane & 15)) * LD + (lane >> 4);
+  int par = 0;
+  for (int c0 = c_begin; c0 < c_end; c0 += KC, par ^= 1) {
+    const float* cur = lds + par * BUF;
+    float* nxt = lds + (par ^ 1) * BUF;
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t) {             // k-step t of chunk c0  ||  tap t of chunk c0+KC
+      float af[2], bf[NT];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) af[i] = cur[arow + i * 16 * LD + t * 4];
+#pragma unroll
+      for (int j = 0; j < NT; ++j) bf[j] = cur[brow + j * 16 * LD + t * 4];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+      build_tap(nxt, c0 + KC, t);
+      load_tap(c0 + 2 * KC, t);
+      // keep hipcc from sinking the re-issued gathers to the loop bottom (it did: the next
+      // iteration then waited vmcnt(0), i.e. the full latency, every chunk)
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();                             // nxt complete, cur free
+  }
+
+  const bool raw = a.splitk > 1;
+  float* ob = raw ? a.partial + ((long long)ksl * a.B + b) * a.Cout * HWo
+                  : a.out + (long long)b * a.Cout * HWo;
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int co = n0 + wn * (BN / 2) + j * 16 + (lane & 15);
+    if (co >= a.Cout) continue;
+    float sc = 1.f, sh = 0.f;
+    if (!raw) {
+      if (a.ep_scale) sc = a.ep_scale[co];
+      if (a.ep_shift) sh = a.ep_shift[co];
+      else if (a.bias) sh = a.bias[co];
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int pp = blockIdx.x * BM + wm * 32 + i * 16 + (lane >> 4) * 4;
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        v[r] = acc[i][j][r] * sc + sh;
+        if (a.relu && !raw) v[r] = fmaxf(v[r], 0.f);
+      }
+      float* dst = ob + (long long)co * HWo + pp;
+      if (pp + 3 < HWo && (HWo & 3) == 0) {
+        *reinterpret_cast<f32x4*>(dst) = f32x4{v[0], v[1], v[2], v[3]};
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (pp + r < HWo) dst[r] = v[r];
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------- split-bf16 kernel ---
+// Same tiling and buffer-load gathers as dcn_fwd_kernel, but the contraction runs on the bf16
+// matrix cores as THREE products of bf16 halves with fp32 accumulation:
+//     a*b ~= ah*bh + ah*bl + al*bh,   x = xh + xl,  xh = bf16(x), xl = bf16(x - xh)
+// (the dropped al*bl term is 2^-16 relative), i.e. an fp32 emulation, not a bf16 result.
+// v_mfma_f32_16x16x32_bf16 takes 16 cycles for 16x16x32 MACs vs 8 x 32 cycles for the same
+// tile on the fp32 16x16x4 form: 3 of them cost 48 vs 256 cycles.  Chunks are 8 input channels
+// = 72 k values, zero-padded to 96 (three 32-deep MFMA steps).  LDS tiles hold the hi and lo
+// halves row-major with 208-byte rows, which makes the 16-byte fragment reads conflict-free.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ void split_bf16(float v, __bf16& hi, __bf16& lo) {
+  hi = (__bf16)v;
+  lo = (__bf16)(v - (float)hi);
+}
+
+template <int BN, int WPS>
+__global__ __launch_bounds__(256, WPS) void dcn_fwd_bf16x3_kernel(DcnFwdArgs a) {
+  constexpr int KC = 8;
+  constexpr int KK = KC * TAPS;          // 72
+  constexpr int KP = 96;                 // padded k extent (3 MFMA steps of 32)
+  constexpr int LDA = KP + 8;            // 104 bf16 = 208 B rows
+  constexpr int NT = BN / 32;
+  constexpr int CPW = KC / 4;            // 2 channels sampled per wave per chunk
+  extern __shared__ float lds[];
+  __bf16* colH = (__bf16*)lds;           // [BM][LDA]
+  __bf16* colL = colH + BM * LDA;
+  __bf16* wH = colL + BM * LDA;          // [BN][LDA]
+  __bf16* wL = wH + BN * LDA;
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int b = blockIdx.z % a.B;
+  const int n0 = blockIdx.y * BN;
+  const int HWo = a.Ho * a.Wo, HW = a.H * a.W;
+  const int p = blockIdx.x * BM + lane;
+  const bool p_ok = p < HWo;
+
+  float cw[TAPS][4];
+  unsigned coff[TAPS][4];
+  {
+    const int ho = p_ok ? p / a.Wo : 0;
+    const int wo = p_ok ? p - ho * a.Wo : 0;
+    const float* off = a.offset + (long long)b * a.offset_bstride;
+    const float* msk = a.mask + (long long)b * a.mask_bstride;
+    float oy[TAPS], ox[TAPS], mk[TAPS];
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t) {
+      oy[t] = p_ok ? off[(long long)(2 * t) * HWo + p] : 0.f;
+      ox[t] = p_ok ? off[(long long)(2 * t + 1) * HWo + p] : 0.f;
+      mk[t] = p_ok ? msk[(long long)t * HWo + p] : 0.f;
+    }
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t) {
+      const int ky = t / 3, kx = t - ky * 3;
+      float m = mk[t];
+      if (a.mask_is_logit) m = 1.f / (1.f + __expf(-m));
+      const float py = (float)(ho * a.stride - a.pad + ky * a.dil) + oy[t];
+      const float px = (float)(wo * a.stride - a.pad + kx * a.dil) + ox[t];
+      const bool inside = p_ok && py > -1.f && px > -1.f && py < (float)a.H && px < (float)a.W;
+      const float fy = floorf(py), fx = floorf(px);
+      const int y0 = (int)fy, x0 = (int)fx;
+      const float ly = py - fy, lx = px - fx;
+      const float hy = 1.f - ly, hx = 1.f - lx;
+      const bool y0ok = y0 >= 0, y1ok = y0 + 1 <= a.H - 1;
+      const bool x0ok = x0 >= 0, x1ok = x0 + 1 <= a.W - 1;
+      const int y0c = min(max(y0, 0), a.H - 1), y1c = min(max(y0 + 1, 0), a.H - 1);
+      const int x0c = min(max(x0, 0), a.W - 1), x1c = min(max(x0 + 1, 0), a.W - 1);
+      cw[t][0] = (inside && y0ok && x0ok) ? hy * hx * m : 0.f;
+      cw[t][1] = (inside && y0ok && x1ok) ? hy * lx * m : 0.f;
+      cw[t][2] = (inside && y1ok && x0ok) ? ly * hx * m : 0.f;
+      cw[t][3] = (inside && y1ok && x1ok) ? ly * lx * m : 0.f;
+      coff[t][0] = inside ? 4u * (unsigned)(y0c * a.W + x0c) : 0u;
+      coff[t][1] = inside ? 4u * (unsigned)(y0c * a.W + x1c) : 0u;
+      coff[t][2] = inside ? 4u * (unsigned)(y1c * a.W + x0c) : 0u;
+      coff[t][3] = inside ? 4u * (unsigned)(y1c * a.W + x1c) : 0u;
+    }
+  }
+
+  f32x4 acc[2][NT];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int wm = wid >> 1, wn = wid & 1;
+  const int Ktot = a.Cin * TAPS;
+  const float* xb = a.x + (long long)b * a.Cin * HW;
+  const int ksl = (a.splitk > 1) ? (int)(blockIdx.z / a.B) : 0;
+  const int c_begin = ksl * a.c_per_split;
+  const int c_end = min(a.Cin, c_begin + a.c_per_split);
+
+  const unsigned plane_bytes = (unsigned)HW * 4u;
+  const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(xb), 0, (int)((unsigned)a.Cin * plane_bytes), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.weight), 0, (int)((unsigned)a.Cout * (unsigned)Ktot * 4u), 0x00020000);
+  // weight staging: thread -> row (tid>>2) [+64 per pass], quarter (tid&3) = 18 consecutive k
+  constexpr int QW = KK / 4;             // 18
+  constexpr int WPASS = BN / 64;
+  const int wrow = tid >> 2, wq = tid & 3;
+  unsigned wbase[WPASS];
+#pragma unroll
+  for (int ps = 0; ps < WPASS; ++ps) {
+    const int co = n0 + ps * 64 + wrow;
+    wbase[ps] = co < a.Cout ? ((unsigned)co * (unsigned)Ktot + (unsigned)(wq * QW)) * 4u : 0xffffffffu;
+  }
+  const int swid = __builtin_amdgcn_readfirstlane(wid);
+
+  // zero the k padding [72, 96) of all four tiles once
+  for (int e = tid; e < (BM + BN) * (KP - KK); e += 256) {
+    const int row = e / (KP - KK), kk = KK + (e - row * (KP - KK));
+    if (row < BM) { colH[row * LDA + kk] = (__bf16)0.f; colL[row * LDA + kk] = (__bf16)0.f; }
+    else { wH[(row - BM) * LDA + kk] = (__bf16)0.f; wL[(row - BM) * LDA + kk] = (__bf16)0.f; }
+  }
+
+  float g[CPW][TAPS][4];
+  float wreg[WPASS][QW];
+  auto issue_loads = [&](int c0) {
+    const unsigned wk = (unsigned)(c0 * TAPS) * 4u;   // in voffset: soffset is not range-checked
+#pragma unroll
+    for (int ps = 0; ps < WPASS; ++ps)
+#pragma unroll
+      for (int i = 0; i < QW; ++i)
+        wreg[ps][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                                     rs_w, wbase[ps] == 0xffffffffu ? 0xffffffffu : wbase[ps] + wk + 4u * i, 0, 0));
+#pragma unroll
+    for (int cc = 0; cc < CPW; ++cc) {
+      const unsigned xsoff = (unsigned)min(c0 + swid * CPW + cc, a.Cin - 1) * plane_bytes;
+#pragma unroll
+      for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          g[cc][t][k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_x, coff[t][k], xsoff, 0));
+    }
+  };
+  auto write_lds = [&](int c0) {
+#pragma unroll
+    for (int cc = 0; cc < CPW; ++cc) {
+      const int cl = swid * CPW + cc;
+      const bool c_ok = c0 + cl < c_end;
+#pragma unroll
+      for (int t = 0; t < TAPS; ++t) {
+        float v = cw[t][0] * g[cc][t][0] + cw[t][1] * g[cc][t][1] + cw[t][2] * g[cc][t][2] +
+                  cw[t][3] * g[cc][t][3];
+        v = c_ok ? v : 0.f;
+        __bf16 h, l;
+        split_bf16(v, h, l);
+        colH[lane * LDA + cl * TAPS + t] = h;
+        colL[lane * LDA + cl * TAPS + t] = l;
+      }
+    }
+#pragma unroll
+    for (int ps = 0; ps < WPASS; ++ps)
+#pragma unroll
+      for (int i = 0; i < QW; ++i) {
+        const bool k_ok = c0 * TAPS + wq * QW + i < c_end * TAPS;
+        __bf16 h, l;
+        split_bf16(k_ok ? wreg[ps][i] : 0.f, h, l);
+        wH[(ps * 64 + wrow) * LDA + wq * QW + i] = h;
+        wL[(ps * 64 + wrow) * LDA + wq * QW + i] = l;
+      }
+  };
+
+  if (c_begin < c_end) issue_loads(c_begin);
+  for (int c0 = c_begin; c0 < c_end; c0 += KC) {
+    __syncthreads();                     // previous chunk's fragment reads are done
+    write_lds(c0);
+    __syncthreads();
+    if (c0 + KC < c_end) issue_loads(c0 + KC);
+    const int arow = (wm * 32 + (lane & 15)) * LDA + 8 * (lane >> 4);
+    const int brow = (wn * (BN / 2) + (lane & 15)) * LDA + 8 * (lane >> 4);
+#pragma unroll
+    for (int ks = 0; ks < KP / 32; ++ks) {
+      bf16x8 ah[2], al[2], bh[NT], bl[NT];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        ah[i] = *reinterpret_cast<const bf16x8*>(colH + arow + i * 16 * LDA + ks * 32);
+        al[i] = *reinterpret_cast<const bf16x8*>(colL + arow + i * 16 * LDA + ks * 32);
+      }
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        bh[j] = *reinterpret_cast<const bf16x8*>(wH + brow + j * 16 * LDA + ks * 32);
+        bl[j] = *reinterpret_cast<const bf16x8*>(wL + brow + j * 16 * LDA + ks * 32);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+        }
+    }
+  }
+
+  const bool raw = a.splitk > 1;
+  float* ob = raw ? a.partial + ((long long)ksl * a.B + b) * a.Cout * HWo
+                  : a.out + (long long)b * a.Cout * HWo;
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int co = n0 + wn * (BN / 2) + j * 16 + (lane & 15);
+    if (co >= a.Cout) continue;
+    float sc = 1.f, sh = 0.f;
+    if (!raw) {
+      if (a.ep_scale) sc = a.ep_scale[co];
+      if (a.ep_shift) sh = a.ep_shift[co];
+      else if (a.bias) sh = a.bias[co];
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int pp = blockIdx.x * BM + wm * 32 + i * 16 + (lane >> 4) * 4;
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        v[r] = acc[i][j][r] * sc + sh;
+        if (a.relu && !raw) v[r] = fmaxf(v[r], 0.f);
+      }
+      float* dst = ob + (long long)co * HWo + pp;
+      if (pp + 3 < HWo && (HWo & 3) == 0) {
+        *reinterpret_cast<f32x4*>(dst) = f32x4{v[0], v[1], v[2], v[3]};
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (pp + r < HWo) dst[r] = v[r];
+      }
+    }
+  }
+}
+
 // Sum the K-split partials and apply bias / folded-BN / ReLU.
 __global__ __launch_bounds__(256) void dcn_splitk_reduce_kernel(DcnFwdArgs a, long long n_per_b) {
   const long long total = (long long)a.B * n_per_b;
@@ -303,7 +730,7 @@ Plan make_plan(int B, int Cin, int Cout, int HWo) {
     p.splitk = s;
   }
   int cps = (Cin + p.splitk - 1) / p.splitk;
-  cps = (cps + kc - 1) / kc * kc;
+  cps = (cps + 7) / 8 * 8;               // whole chunks for both the fp32 (4) and bf16x3 (8) kernels
   p.c_per_split = cps;
   p.splitk = (Cin + cps - 1) / cps;
   return p;
@@ -315,6 +742,40 @@ int launch(const DcnFwdArgs& a, hipStream_t st) {
   const size_t lds = (size_t)(BM + BN) * LD * sizeof(float);
   dim3 grid((a.Ho * a.Wo + BM - 1) / BM, (a.Cout + BN - 1) / BN, a.B * a.splitk);
   hipLaunchKernelGGL((dcn_fwd_kernel<BN, KC, WPS>), grid, dim3(256), lds, st, a);
+  if (a.splitk > 1) {
+    const long long n_per_b = (long long)a.Cout * a.Ho * a.Wo;
+    long long nb = ((long long)a.B * n_per_b + 255) / 256;
+    if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(dcn_splitk_reduce_kernel, dim3((unsigned)nb), dim3(256), 0, st, a, n_per_b);
+  }
+  return cp_launch_status();
+}
+
+template <int BN, int WPS>
+int launch_pipe(const DcnFwdArgs& a, hipStream_t st) {
+  const size_t lds = (size_t)2 * (BM + BN) * 37 * sizeof(float);
+  if (lds > 64 * 1024)
+    (void)hipFuncSetAttribute((const void*)dcn_fwd_pipe_kernel<BN, WPS>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  dim3 grid((a.Ho * a.Wo + BM - 1) / BM, (a.Cout + BN - 1) / BN, a.B * a.splitk);
+  hipLaunchKernelGGL((dcn_fwd_pipe_kernel<BN, WPS>), grid, dim3(256), lds, st, a);
+  if (a.splitk > 1) {
+    const long long n_per_b = (long long)a.Cout * a.Ho * a.Wo;
+    long long nb = ((long long)a.B * n_per_b + 255) / 256;
+    if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(dcn_splitk_reduce_kernel, dim3((unsigned)nb), dim3(256), 0, st, a, n_per_b);
+  }
+  return cp_launch_status();
+}
+
+template <int BN, int WPS>
+int launch_bf16x3(const DcnFwdArgs& a, hipStream_t st) {
+  const size_t lds = (size_t)2 * (BM + BN) * 104 * 2;      // hi + lo halves, 104 bf16 per row
+  if (lds > 64 * 1024)
+    (void)hipFuncSetAttribute((const void*)dcn_fwd_bf16x3_kernel<BN, WPS>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  dim3 grid((a.Ho * a.Wo + BM - 1) / BM, (a.Cout + BN - 1) / BN, a.B * a.splitk);
+  hipLaunchKernelGGL((dcn_fwd_bf16x3_kernel<BN, WPS>), grid, dim3(256), lds, st, a);
   if (a.splitk > 1) {
     const long long n_per_b = (long long)a.Cout * a.Ho * a.Wo;
     long long nb = ((long long)a.B * n_per_b + 255) / 256;
@@ -344,8 +805,9 @@ extern "C" int cp_dcn_v2_forward(const cp_dcn_shape* s, const float* x, const fl
                                  int64_t offset_bstride, const float* mask,
                                  int64_t mask_bstride, int32_t mask_is_logit,
                                  const float* weight, const float* bias, const float* ep_scale,
-                                 const float* ep_shift, int32_t relu, float* out, void* workspace,
-                                 size_t workspace_bytes, void* stream) {
+                                 const float* ep_shift, int32_t relu, int32_t contraction,
+                                 float* out, void* workspace, size_t workspace_bytes,
+                                 void* stream) {
   CP_CHECK_ARG(s && x && offset && mask && weight && out);
   CP_CHECK_ARG(s->B > 0 && s->Cin > 0 && s->H > 0 && s->W > 0 && s->Cout > 0);
   CP_CHECK_ARG(s->stride > 0 && s->dil > 0 && s->pad >= 0);
@@ -374,6 +836,16 @@ extern "C" int cp_dcn_v2_forward(const cp_dcn_shape* s, const float* x, const fl
   }
 #endif
   hipStream_t st = (hipStream_t)stream;
+  CP_CHECK_ARG(contraction == CP_DCN_F32 || contraction == CP_DCN_BF16X3);
+  if ((unsigned long long)s->Cout * s->Cin * 9ull * 4ull >= 0xE0000000ull) return CP_EUNSUPPORTED;
+  if (contraction == CP_DCN_BF16X3 && p.bn <= 128 && (p.c_per_split % 8) == 0) {
+    if (p.bn == 64) return launch_bf16x3<64, 2>(a, st);
+    return launch_bf16x3<128, 1>(a, st);
+  }
+  if (!getenv("CP_DCN_PHASED")) {                 // interleaved kernel (default)
+    if (p.bn == 64) return launch_pipe<64, 3>(a, st);
+    if (p.bn == 128) return launch_pipe<128, 2>(a, st);
+  }
   if (p.bn == 64) return launch<64, 4, 2>(a, st);
   if (p.bn == 128) return launch<128, 4, 1>(a, st);
   return launch<256, 4, 1>(a, st);

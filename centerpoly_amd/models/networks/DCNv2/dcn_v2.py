@@ -26,7 +26,7 @@ def _shape(x, weight, stride, pad, dil, dg):
 
 
 def dcn_v2_forward_raw(x, om, weight, bias, stride=1, pad=1, dil=1, dg=1, ep_scale=None,
-                       ep_shift=None, relu=False):
+                       ep_shift=None, relu=False, contraction="f32"):
     """Forward on the raw offset/mask tensor `om` [B, 3*kh*kw, Ho, Wo] (mask as logits).
     Optional fused per-channel epilogue out = act(acc*ep_scale + ep_shift)."""
     L = _C.lib()
@@ -42,7 +42,7 @@ def dcn_v2_forward_raw(x, om, weight, bias, stride=1, pad=1, dil=1, dg=1, ep_sca
     end = timer.start(("dcn_fwd", s.Cin, s.Cout, Ho, Wo)) if timer is not None else None
     rc = L.cp_dcn_v2_forward(s, _C.ptr(x), _C.ptr(om), bs, mask_ptr, bs, 1, _C.ptr(weight),
                              _C.ptr(bias), _C.ptr(ep_scale), _C.ptr(ep_shift), 1 if relu else 0,
-                             _C.ptr(out), _C.ptr(ws), nws, _C.stream())
+                             _C.DCN_CONTRACTION[contraction], _C.ptr(out), _C.ptr(ws), nws, _C.stream())
     if end is not None:
         end.record()
     _C.check(rc, "cp_dcn_v2_forward")
@@ -128,4 +128,4 @@ class DCN(nn.Module):
         om = self.conv_offset_mask(x)
         return dcn_v2_forward_raw(x.contiguous(), om.contiguous(), self.weight, None, self.stride,
                                   self.padding, self.dilation, self.deformable_groups, ep_scale,
-                                  ep_shift, relu)
+                                  ep_shift, relu, getattr(self, "contraction", "f32"))

@@ -370,14 +370,17 @@ class DLASeg(nn.Module):
                 fill_fc_weights(fc)
             self.__setattr__(head, fc)
 
-    def prepare_inference(self):
+    def prepare_inference(self, dcn_contraction="f32"):
         """Fold every BatchNorm into its convolution / DCN epilogue and concatenate the heads'
         first 3x3 convolutions into one (call after loading weights, in eval mode).  Undone by
-        train()."""
+        train().  dcn_contraction: "f32" (exact fp32 MFMA) or "bf16x3" (split-bf16 emulation,
+        ~2^-16 relative error, inference only)."""
         self.eval()
         for m in self.modules():
             if hasattr(m, "fold"):
                 m.fold()
+            if isinstance(m, DCN):
+                m.contraction = dcn_contraction
         self._heads_cat = None
         fcs = [getattr(self, h) for h in self.heads]
         if all(isinstance(fc, nn.Sequential) and len(fc) == 3 for fc in fcs):

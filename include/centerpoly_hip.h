@@ -61,6 +61,13 @@ enum {
 /* representation of the polygon head (src/lib/opts.py `--rep`) */
 enum { CP_REP_CARTESIAN = 0, CP_REP_POLAR = 1, CP_REP_POLAR_FIXED = 2 };
 
+/* contraction arithmetic of cp_dcn_v2_forward */
+enum {
+  CP_DCN_F32 = 0,    /* fp32 MFMA, exact fp32 fma chain                                        */
+  CP_DCN_BF16X3 = 1  /* split-bf16: a*b ~ ah*bh + ah*bl + al*bh on bf16 MFMA, fp32 accumulate;
+                        ~2^-16 relative error, 4x less matrix-core time (inference option)   */
+};
+
 /* regression flavour for cp_gather_l1_* */
 enum {
   CP_L1_PLAIN = 0,       /* RegL1Loss / PolyLoss cartesian: sum |p*m - t*m|            */
@@ -102,8 +109,9 @@ size_t cp_dcn_v2_forward_workspace_bytes(const cp_dcn_shape* s); /* 0 for most s
 int cp_dcn_v2_forward(const cp_dcn_shape* s, const float* x, const float* offset,
                       int64_t offset_bstride, const float* mask, int64_t mask_bstride,
                       int32_t mask_is_logit, const float* weight, const float* bias,
-                      const float* ep_scale, const float* ep_shift, int32_t relu, float* out,
-                      void* workspace, size_t workspace_bytes, void* stream);
+                      const float* ep_scale, const float* ep_shift, int32_t relu,
+                      int32_t contraction, float* out, void* workspace, size_t workspace_bytes,
+                      void* stream);
 
 /* Backward.  grad_* outputs may be NULL to skip that gradient.  grad_x,
  * grad_weight and grad_bias are ACCUMULATED INTO (caller zero-fills);

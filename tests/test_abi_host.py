@@ -40,7 +40,7 @@ def test_argument_validation_without_gpu():
                                None, 0, None) == -1
     assert L.cp_sigmoid_focal_forward(None, None, 16, None, None, None, 0, None) == -1
     s = _C.DcnShape(1, 8, 4, 4, 8, 3, 3, 1, 1, 1, 1)
-    assert L.cp_dcn_v2_forward(s, None, None, 0, None, 0, 0, None, None, None, None, 0, None,
+    assert L.cp_dcn_v2_forward(s, None, None, 0, None, 0, 0, None, None, None, None, 0, 0, None,
                                None, 0, None) == -1
     # small-spatial, wide layers split K and need a workspace; big maps do not
     assert L.cp_dcn_v2_forward_workspace_bytes(_C.DcnShape(1, 512, 32, 64, 256, 3, 3, 1, 1, 1, 1)) > 0

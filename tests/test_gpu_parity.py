@@ -338,6 +338,24 @@ def test_dcn_forward_vs_oracle(shape):
     np.testing.assert_allclose(out.numpy(), ref.numpy(), rtol=1e-3, atol=2e-5 * scale)
 
 
+BF16X3_SHAPES = [(1, 64, 64, 32, 64), (2, 24, 40, 13, 19), (1, 256, 128, 16, 32), (1, 512, 64, 8, 16)]
+
+
+@pytest.mark.parametrize("shape", BF16X3_SHAPES, ids=lambda s: "x".join(map(str, s)))
+def test_dcn_forward_split_bf16_contraction(shape):
+    """Inference option: split-bf16 (hi/lo, 3 bf16 MFMAs, fp32 accumulate).  Tolerance is the
+    north-star's 1e-3 relative on the layer output; the measured error is ~1e-5."""
+    from centerpoly_amd.models.networks.DCNv2.dcn_v2 import dcn_v2_forward_raw
+    B, Cin, Cout, H, W = shape
+    x, om, w, b = _dcn_inputs("%dx%d" % (Cin, Cout), *shape)
+    ref = _dcn_ref(x, om, w, b)
+    out = dcn_v2_forward_raw(g(x), g(om), g(w), g(b), contraction="bf16x3").cpu()
+    scale = ref.abs().max().item()
+    err = (out - ref).abs().max().item() / scale
+    assert err < 1e-4, err
+    np.testing.assert_allclose(out.numpy(), ref.numpy(), rtol=1e-3, atol=1e-4 * scale)
+
+
 def test_dcn_large_offsets_and_borders():
     """Offsets that throw samples far outside the image (zero contribution) and exactly
     onto integer / border positions."""
@@ -501,7 +519,7 @@ def _load_by_name(model, gold):
     return model.to(DEV).eval()
 
 
-@pytest.mark.parametrize("fused", [False, True], ids=["plain", "prepare_inference"])
+@pytest.mark.parametrize("fused", [False, True, "bf16x3"], ids=["plain", "prepare_inference", "bf16x3"])
 def test_dla34_forward_vs_reference_golden(fused, golden):
     """Reference DLASeg wiring (with the oracle's DCN in the plugin slot) vs the HIP path, with and
     without the inference fusions (folded BN, fused epilogues, concatenated heads)."""
@@ -509,7 +527,7 @@ def test_dla34_forward_vs_reference_golden(fused, golden):
     gold = golden("net_dla34")
     m = _load_by_name(create_model("dla_34", dict(cases.HEADS), 256), gold)
     if fused:
-        m.prepare_inference()
+        m.prepare_inference(dcn_contraction="bf16x3" if fused == "bf16x3" else "f32")
     with torch.no_grad():
         out = m(g(cases.net_input("dla")))[0]
     for h in dict(cases.HEADS):

@@ -19,7 +19,7 @@ def run(ci, co, H, W, n=10):
     bs = 27 * H * W
     def call():
         rc = L.cp_dcn_v2_forward(s, _C.ptr(x), _C.ptr(om), bs, ctypes.c_void_p(om.data_ptr() + 72 * H * W), bs, 1,
-                                 _C.ptr(w), _C.ptr(b), None, None, 0, _C.ptr(out), _C.ptr(ws), nws, _C.stream())
+                                 _C.ptr(w), _C.ptr(b), None, None, 0, 0, _C.ptr(out), _C.ptr(ws), nws, _C.stream())
         assert rc == 0, rc
     for _ in range(3): call()
     torch.cuda.synchronize()
