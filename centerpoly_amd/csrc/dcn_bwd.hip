@@ -340,24 +340,44 @@ __global__ __launch_bounds__(256, WPS) void dcn_bwd_data_tiled_kernel(DcnBwdArgs
     wT[co * LDW + KK + (e - co * (LDW - KK))] = 0.f;
   }
 
-  float wreg[WPT], xr[RPT];
+  // Region cells and weights are read with raw buffer loads: wave-uniform descriptor, per-lane
+  // 32-bit byte offset fixed for the whole channel loop (cells outside the image carry an
+  // out-of-range offset and read 0), channel plane in the scalar offset (clamped: soffset is not
+  // range-checked).  Wave w stages, consumes and flushes the region of ITS channel c0 + w.
+  constexpr int RPW = RSZ / 64;            // region cells per lane (9)
+  static_assert(RSZ % 64 == 0, "one wave sweeps a region in whole passes");
+  const unsigned plane_bytes = (unsigned)HW * 4u;
+  const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(xb), 0, (int)((unsigned)a.Cin * plane_bytes), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.weight), 0, (int)((unsigned)a.Cout * (unsigned)Ktot * 4u), 0x00020000);
+  unsigned roff[RPW];
+#pragma unroll
+  for (int i = 0; i < RPW; ++i) {
+    const int e = lane + 64 * i;
+    const int ry = e / RWP, rx = e - ry * RWP;
+    const int gy_ = ry0 + ry, gx_ = rx0 + rx;
+    const bool ok = rx < RW && gy_ >= 0 && gy_ < a.H && gx_ >= 0 && gx_ < a.W;
+    roff[i] = ok ? 4u * (unsigned)(gy_ * a.W + gx_) : 0xf0000000u;
+  }
+  unsigned woff[WPT];
+#pragma unroll
+  for (int i = 0; i < WPT; ++i) {
+    const int idx = tid + i * 256;
+    const int co = idx / KK, kk = idx - co * KK;
+    woff[i] = (idx < CP * KK && co < a.Cout) ? ((unsigned)co * (unsigned)Ktot + (unsigned)kk) * 4u : 0xf0000000u;
+  }
+  const int swid = __builtin_amdgcn_readfirstlane(wid);
+  float wreg[WPT], xr[RPW];
   auto issue = [&](int c0) {
+    const unsigned wk = (unsigned)(c0 * TAPS) * 4u;       // rides in voffset (range-checked)
 #pragma unroll
-    for (int i = 0; i < WPT; ++i) {
-      const int idx = tid + i * 256;
-      const int co = idx / KK, kk = idx - co * KK;
-      const int kg = c0 * TAPS + kk;
-      wreg[i] = (idx < CP * KK && co < a.Cout && kg < Ktot) ? a.weight[(long long)co * Ktot + kg] : 0.f;
-    }
+    for (int i = 0; i < WPT; ++i)
+      wreg[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_w, woff[i] + wk, 0, 0));
+    const unsigned xsoff = (unsigned)min(c0 + swid, a.Cin - 1) * plane_bytes;
 #pragma unroll
-    for (int i = 0; i < RPT; ++i) {
-      const int e = tid + i * 256;
-      const int cl = e / RSZ, rem = e - cl * RSZ;
-      const int ry = rem / RWP, rx = rem - ry * RWP;
-      const int gy_ = ry0 + ry, gx_ = rx0 + rx, c = c0 + cl;
-      const bool ok = e < KC * RSZ && rx < RW && c < a.Cin && gy_ >= 0 && gy_ < a.H && gx_ >= 0 && gx_ < a.W;
-      xr[i] = ok ? xb[(long long)c * HW + gy_ * a.W + gx_] : 0.f;
-    }
+    for (int i = 0; i < RPW; ++i)
+      xr[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_x, roff[i], xsoff, 0));
   };
   issue(0);
   for (int c0 = 0; c0 < a.Cin; c0 += KC) {
@@ -371,10 +391,7 @@ __global__ __launch_bounds__(256, WPS) void dcn_bwd_data_tiled_kernel(DcnBwdArgs
       }
     }
 #pragma unroll
-    for (int i = 0; i < RPT; ++i) {
-      const int e = tid + i * 256;
-      if (e < KC * RSZ) xreg[e] = xr[i];
-    }
+    for (int i = 0; i < RPW; ++i) xreg[swid * RSZ + lane + 64 * i] = xr[i];
     __syncthreads();
     if (c0 + KC < a.Cin && !CP_ABL(8)) issue(c0 + KC);   // next chunk's loads fly during the MFMA phase
 
@@ -462,18 +479,18 @@ __global__ __launch_bounds__(256, WPS) void dcn_bwd_data_tiled_kernel(DcnBwdArgs
       }
     }
     __syncthreads();
-    // ---- flush the accumulated region: one coalesced global atomic per touched cell ----
-    if (gxb && !CP_ABL(2)) {
-      for (int e = tid; e < KC * RSZ; e += 256) {
-        const long long qv = (long long)greg[e];
+    // ---- flush: each wave empties its own channel's region, one coalesced global atomic per
+    // touched in-image cell (the cell's byte offset is the staging offset) ----
+    if (gxb && !CP_ABL(2) && c < a.Cin) {
+      unsigned long long* gw_ = greg + swid * RSZ;
+      float* gplane = gxb + (long long)c * HW;
+#pragma unroll
+      for (int i = 0; i < RPW; ++i) {
+        const long long qv = (long long)gw_[lane + 64 * i];
         if (qv != 0) {
-          greg[e] = 0ull;
-          const float v = (float)((double)qv * fx_inv);
-          const int cl = e / RSZ, rem = e - cl * RSZ;
-          const int ry = rem / RWP, rx = rem - ry * RWP;
-          const int gy_ = ry0 + ry, gx_ = rx0 + rx, cc = c0 + cl;
-          if (cc < a.Cin && gy_ >= 0 && gy_ < a.H && gx_ >= 0 && gx_ < a.W)
-            atomicAdd(&gxb[(long long)cc * HW + gy_ * a.W + gx_], v);
+          gw_[lane + 64 * i] = 0ull;
+          if (roff[i] != 0xf0000000u)
+            atomicAdd(gplane + (roff[i] >> 2), (float)((double)qv * fx_inv));
         }
       }
     }
@@ -643,6 +660,14 @@ __global__ __launch_bounds__(256, WPS) void dcn_bwd_weight_tiled_kernel(DcnBwdAr
   const int tiles = HWo / BM;
   const float* gob = a.go + (long long)b * a.Cout * HWo;
   const float* xb = a.x + (long long)b * a.Cin * HW;
+  // raw buffer loads (see the data kernel): per-lane 32-bit offsets, range-checked by hardware
+  constexpr int RPW = RSZ / 64;
+  const unsigned plane_bytes = (unsigned)HW * 4u;
+  const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(xb), 0, (int)((unsigned)a.Cin * plane_bytes), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_go = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(gob), 0, (int)((unsigned)a.Cout * (unsigned)HWo * 4u), 0x00020000);
+  const int swid = __builtin_amdgcn_readfirstlane(wid);
 
   f32x4 acc[WCH][MT][3];
 #pragma unroll
@@ -679,33 +704,37 @@ __global__ __launch_bounds__(256, WPS) void dcn_bwd_weight_tiled_kernel(DcnBwdAr
                    : (inside ? -1 : -2);
       }
     }
-    float xr[RPT];
-    auto issue = [&](int c0) {
+    unsigned roff[RPW];                    // this wave's region cells (channel c0 + w), per tile
 #pragma unroll
-      for (int i = 0; i < RPT; ++i) {
-        const int e = tid + i * 256;
-        const int cl = e / RSZ, rem = e - cl * RSZ;
-        const int ry = rem / RWP, rx = rem - ry * RWP;
-        const int gy_ = ry0 + ry, gx_ = rx0 + rx, c = c0 + cl;
-        const bool ok = e < KC * RSZ && rx < RW && c < a.Cin && gy_ >= 0 && gy_ < a.H && gx_ >= 0 && gx_ < a.W;
-        xr[i] = ok ? xb[(long long)c * HW + gy_ * a.W + gx_] : 0.f;
-      }
+    for (int i = 0; i < RPW; ++i) {
+      const int e = lane + 64 * i;
+      const int ry = e / RWP, rx = e - ry * RWP;
+      const int gy_ = ry0 + ry, gx_ = rx0 + rx;
+      const bool ok = rx < RW && gy_ >= 0 && gy_ < a.H && gx_ >= 0 && gx_ < a.W;
+      roff[i] = ok ? 4u * (unsigned)(gy_ * a.W + gx_) : 0xf0000000u;
+    }
+    float xr[RPW];
+    auto issue = [&](int c0) {
+      const unsigned xsoff = (unsigned)min(c0 + swid, a.Cin - 1) * plane_bytes;
+#pragma unroll
+      for (int i = 0; i < RPW; ++i)
+        xr[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_x, roff[i], xsoff, 0));
     };
     issue(cs0);
     __syncthreads();                       // previous tile's MFMA reads of goT/colT are done
-    for (int idx = tid; idx < SLAB * BM; idx += 256) {
-      const int co = idx / BM, pp = idx - co * BM;
-      goT[pp * LDS_ + co] = (co0 + co < a.Cout) ? gob[(long long)(co0 + co) * HWo + p0 + pp] : 0.f;
+    {                                      // grad_out tile: thread -> pixel lane, rows wid, wid+4, ...
+      const unsigned gbase = ((unsigned)(co0 + swid) * (unsigned)HWo + (unsigned)(p0 + lane)) * 4u;
+#pragma unroll
+      for (int i = 0; i < SLAB / 4; ++i)   // rows past Cout are past num_records and read 0
+        goT[lane * LDS_ + swid + 4 * i] = __builtin_bit_cast(
+            float, __builtin_amdgcn_raw_buffer_load_b32(rs_go, gbase + (unsigned)(4 * i) * (unsigned)HWo * 4u, 0, 0));
     }
 #pragma unroll
     for (int h = 0; h < WCH; ++h) {
       const int c0 = cs0 + h * KC;
       __syncthreads();                     // colT / xreg free again
 #pragma unroll
-      for (int i = 0; i < RPT; ++i) {
-        const int e = tid + i * 256;
-        if (e < KC * RSZ) xreg[e] = xr[i];
-      }
+      for (int i = 0; i < RPW; ++i) xreg[swid * RSZ + lane + 64 * i] = xr[i];
       __syncthreads();
       if (h + 1 < WCH) issue(c0 + KC);     // next chunk's region loads fly during sampling + MFMA
       // ---- sample: wave w handles channel c0 + w ----
