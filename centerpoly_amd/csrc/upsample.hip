@@ -123,3 +123,102 @@ extern "C" int cp_bias_act_inplace(float* y, const float* bias, const float* res
                      bias, residual, C, (long long)HW, relu);
   return cp_launch_status();
 }
+
+// ------------------------------------------------- depth-wise up-sampling, backward ---
+// Training path of IDAUp's `up` (+ skip add): grad_skip = grad_out (identity, done by the
+// caller), grad_x = the stride-f depth-wise correlation of grad_out with the same 2f x 2f
+// kernel, grad_w[c][ky][kx] = sum_{b,iy,ix} x[b,c,iy,ix] * go[b,c,iy*f-pad+ky, ix*f-pad+kx].
+// Both are memory-bound streaming passes over grad_out (each go element is read once per pass).
+namespace {
+
+template <int F>
+__global__ __launch_bounds__(256) void dw_up_bwd_data_kernel(const float* __restrict__ go,
+                                                             const float* __restrict__ w,
+                                                             float* __restrict__ gx, int C, int H,
+                                                             int W) {
+  constexpr int KS = 2 * F, PAD = F / 2;
+  const int Ho = H * F, Wo = W * F;
+  const int bc = blockIdx.z, c = bc % C;
+  const int iy = blockIdx.y;
+  const int ix = blockIdx.x * 256 + threadIdx.x;
+  if (ix >= W) return;
+  const float* gp = go + (long long)bc * Ho * Wo;
+  const float* wc = w + (long long)c * KS * KS;
+  float s = 0.f;
+#pragma unroll
+  for (int ky = 0; ky < KS; ++ky) {
+    const int oy = iy * F - PAD + ky;
+    if (oy < 0 || oy >= Ho) continue;
+#pragma unroll
+    for (int kx = 0; kx < KS; ++kx) {
+      const int ox = ix * F - PAD + kx;
+      if (ox < 0 || ox >= Wo) continue;
+      s += gp[(long long)oy * Wo + ox] * wc[ky * KS + kx];
+    }
+  }
+  gx[((long long)bc * H + iy) * W + ix] = s;
+}
+
+// grid = (row segments, C, B): each workgroup reduces its rows into KS*KS partial sums and adds
+// them to grad_w with float atomics (KS*KS <= 256 values per workgroup).
+template <int F>
+__global__ __launch_bounds__(256) void dw_up_bwd_weight_kernel(const float* __restrict__ x,
+                                                               const float* __restrict__ go,
+                                                               float* __restrict__ gw, int C, int H,
+                                                               int W, int rows_per_block) {
+  constexpr int KS = 2 * F, PAD = F / 2, NK = KS * KS;
+  const int Ho = H * F, Wo = W * F;
+  const int c = blockIdx.y, b = blockIdx.z;
+  const int bc = b * C + c;
+  const float* xp = x + (long long)bc * H * W;
+  const float* gp = go + (long long)bc * Ho * Wo;
+  const int y0 = blockIdx.x * rows_per_block, y1 = min(H, y0 + rows_per_block);
+  // thread -> (tap, pixel stripe): 256 threads = NK taps x (256/NK) stripes (NK = 16 or 64)
+  constexpr int STRIPES = 256 / (NK > 256 ? 256 : NK);
+  const int tap = threadIdx.x % NK, stripe = threadIdx.x / NK;
+  const int ky = tap / KS, kx = tap - ky * KS;
+  float s = 0.f;
+  if (NK <= 256) {
+    for (int iy = y0; iy < y1; ++iy) {
+      const int oy = iy * F - PAD + ky;
+      if (oy < 0 || oy >= Ho) continue;
+      for (int ix = stripe; ix < W; ix += STRIPES) {
+        const int ox = ix * F - PAD + kx;
+        if (ox < 0 || ox >= Wo) continue;
+        s += xp[iy * W + ix] * gp[(long long)oy * Wo + ox];
+      }
+    }
+  }
+  __shared__ float red[256];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  if (threadIdx.x < NK) {
+    float t = 0.f;
+    for (int q = 0; q < STRIPES; ++q) t += red[q * NK + threadIdx.x];
+    if (t != 0.f) atomicAdd(&gw[(long long)c * NK + threadIdx.x], t);
+  }
+}
+
+}  // namespace
+
+extern "C" int cp_depthwise_up_backward(const float* x, const float* weight, const float* grad_out,
+                                        float* grad_x, float* grad_weight, int32_t B, int32_t C,
+                                        int32_t H, int32_t W, int32_t f, void* stream) {
+  CP_CHECK_ARG(weight && grad_out && B > 0 && C > 0 && H > 0 && W > 0);
+  if (f != 2 && f != 4) return CP_EUNSUPPORTED;          // 2f x 2f taps must fit 256 threads
+  if ((long long)B * C > 65535 || H > 65535 || B > 65535 || C > 65535) return CP_EUNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  if (grad_x) {
+    dim3 grid((W + 255) / 256, H, B * C);
+    if (f == 2) hipLaunchKernelGGL(dw_up_bwd_data_kernel<2>, grid, dim3(256), 0, st, grad_out, weight, grad_x, C, H, W);
+    else hipLaunchKernelGGL(dw_up_bwd_data_kernel<4>, grid, dim3(256), 0, st, grad_out, weight, grad_x, C, H, W);
+  }
+  if (grad_weight) {
+    CP_CHECK_ARG(x);
+    const int rows = 8;
+    dim3 grid((H + rows - 1) / rows, C, B);
+    if (f == 2) hipLaunchKernelGGL(dw_up_bwd_weight_kernel<2>, grid, dim3(256), 0, st, x, grad_out, grad_weight, C, H, W, rows);
+    else hipLaunchKernelGGL(dw_up_bwd_weight_kernel<4>, grid, dim3(256), 0, st, x, grad_out, grad_weight, C, H, W, rows);
+  }
+  return cp_launch_status();
+}

@@ -291,6 +291,37 @@ def depthwise_up_add(x, up, skip):
     return out
 
 
+class _DepthwiseUpAdd(torch.autograd.Function):
+    """up(x) + skip for training: forward = the fused kernel, backward = two streaming kernels
+    (grad_x, grad_weight); grad_skip is grad_out itself."""
+
+    @staticmethod
+    def forward(ctx, x, weight, skip, f):
+        L = _C.lib()
+        x, skip = x.contiguous(), skip.contiguous()
+        B, C, H, W = x.shape
+        out = torch.empty((B, C, H * f, W * f), dtype=torch.float32, device=x.device)
+        rc = L.cp_depthwise_up_forward(_C.ptr(x), _C.ptr(weight), _C.ptr(skip), _C.ptr(out), B, C, H,
+                                       W, f, _C.stream())
+        _C.check(rc, "cp_depthwise_up_forward")
+        ctx.save_for_backward(x, weight)
+        ctx.f = f
+        return out
+
+    @staticmethod
+    def backward(ctx, go):
+        x, weight = ctx.saved_tensors
+        L = _C.lib()
+        go = go.contiguous()
+        B, C, H, W = x.shape
+        gx = torch.empty_like(x)
+        gw = torch.zeros_like(weight)
+        rc = L.cp_depthwise_up_backward(_C.ptr(x), _C.ptr(weight), _C.ptr(go), _C.ptr(gx), _C.ptr(gw),
+                                        B, C, H, W, ctx.f, _C.stream())
+        _C.check(rc, "cp_depthwise_up_backward")
+        return gx, gw, go, None
+
+
 class IDAUp(nn.Module):
     def __init__(self, o, channels, up_f):
         super().__init__()
@@ -308,9 +339,11 @@ class IDAUp(nn.Module):
         for i in range(startp + 1, endp):
             k = i - startp
             up, proj = getattr(self, "up_%d" % k), getattr(self, "proj_%d" % k)
-            if fused and layers[i].is_cuda and up.stride[0] in (2, 4, 8) \
-                    and (layers[i].shape[3] * up.stride[0]) % 4 == 0:
+            aligned = layers[i].is_cuda and (layers[i].shape[3] * up.stride[0]) % 4 == 0
+            if fused and aligned and up.stride[0] in (2, 4, 8):
                 summed = depthwise_up_add(proj(layers[i]), up, layers[i - 1])
+            elif not fused and aligned and up.stride[0] in (2, 4):
+                summed = _DepthwiseUpAdd.apply(proj(layers[i]), up.weight, layers[i - 1], up.stride[0])
             else:
                 summed = up(proj(layers[i])) + layers[i - 1]
             layers[i] = getattr(self, "node_%d" % k)(summed)

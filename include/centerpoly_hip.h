@@ -130,9 +130,13 @@ int cp_dcn_v2_backward(const cp_dcn_shape* s, const float* x, const float* offse
  * groups = C, no bias; src/lib/models/networks/pose_dla_dcn.py:372-375) fused with
  * the `+ layers[i-1]` that follows it (:381-387).
  *   x [B,C,H,W], weight [C,1,2f,2f], skip [B,C,H*f,W*f] or NULL -> out [B,C,H*f,W*f]
- * f in {2,4,8}.  Forward only (training keeps the autograd path). */
+ * f in {2,4,8} forward; backward for f in {2,4}: grad_x is overwritten, grad_weight is
+ * ACCUMULATED INTO (caller zero-fills); grad_skip = grad_out is the caller's business. */
 int cp_depthwise_up_forward(const float* x, const float* weight, const float* skip, float* out,
                             int32_t B, int32_t C, int32_t H, int32_t W, int32_t f, void* stream);
+int cp_depthwise_up_backward(const float* x, const float* weight, const float* grad_out,
+                             float* grad_x, float* grad_weight, int32_t B, int32_t C, int32_t H,
+                             int32_t W, int32_t f, void* stream);
 
 /* y <- act(y + bias[c] + residual) in place (fp32 NCHW, HW = H*W): the epilogue of a library
  * convolution whose BatchNorm was folded (inference).  bias / residual may be NULL. */

@@ -496,6 +496,31 @@ def test_depthwise_up_add_vs_conv_transpose(f, C, H, W):
     np.testing.assert_allclose(out.numpy(), ref.numpy(), rtol=1e-5, atol=1e-6)
 
 
+@pytest.mark.parametrize("f,C,H,W", [(2, 16, 12, 18), (4, 6, 7, 9), (2, 64, 8, 64)])
+def test_depthwise_up_add_backward_vs_autograd(f, C, H, W):
+    from centerpoly_amd.models.networks.pose_dla_dcn import _DepthwiseUpAdd, fill_up_weights
+    up = torch.nn.ConvTranspose2d(C, C, f * 2, stride=f, padding=f // 2, groups=C, bias=False)
+    fill_up_weights(up)
+    with torch.no_grad():
+        up.weight.add_(T(synth.normal("upb/w%d" % f, tuple(up.weight.shape), 0, 0.05)))
+    x = synth.normal("upb/x%d" % f, (2, C, H, W))
+    skip = synth.normal("upb/s%d" % f, (2, C, H * f, W * f))
+    gout = synth.normal("upb/g%d" % f, (2, C, H * f, W * f))
+    xc, sc = T(x).requires_grad_(True), T(skip).requires_grad_(True)
+    wc = up.weight.detach().clone().requires_grad_(True)
+    ref = torch.nn.functional.conv_transpose2d(xc, wc, None, stride=f, padding=f // 2, groups=C) + sc
+    ref.backward(T(gout))
+    xd, sd = g(x).requires_grad_(True), g(skip).requires_grad_(True)
+    wd = up.weight.detach().to(DEV).requires_grad_(True)
+    out = _DepthwiseUpAdd.apply(xd, wd, sd, f)
+    out.backward(g(gout))
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref.detach().numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(xd.grad.cpu().numpy(), xc.grad.numpy(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(sd.grad.cpu().numpy(), sc.grad.numpy(), rtol=0, atol=0)
+    np.testing.assert_allclose(wd.grad.cpu().numpy(), wc.grad.numpy(), rtol=1e-3,
+                               atol=1e-4 * wc.grad.abs().max().item())
+
+
 def test_folded_conv_epilogue_matches_bn_relu():
     """BasicBlock in eval mode: folded conv + fused bias/residual/ReLU pass == conv, BN, add, ReLU."""
     from centerpoly_amd.models.networks.pose_dla_dcn import BasicBlock
