@@ -46,6 +46,11 @@ _SIGNATURES = {
                                      _P, _P, c_int64, _P, c_int64, _P, _P, _P, c_size_t, _P]),
     "cp_depthwise_up_forward": (c_int32, [_P, _P, _P, _P] + [c_int32] * 5 + [_P]),
     "cp_depthwise_up_backward": (c_int32, [_P, _P, _P, _P, _P] + [c_int32] * 5 + [_P]),
+    "cp_bn_workspace_bytes": (c_size_t, [c_int32, c_int32, c_int64]),
+    "cp_bn_act_forward_train": (c_int32, [_P] * 9 + [c_float, c_float, c_int32, c_int32, c_int32, c_int64,
+                                                    _P, c_size_t, _P]),
+    "cp_bn_act_backward": (c_int32, [_P] * 6 + [c_int32] + [_P] * 4 + [c_int32, c_int32, c_int64, _P,
+                                                                       c_size_t, _P]),
     "cp_bias_act_inplace": (c_int32, [_P, _P, _P, c_int32, c_int32, c_int64, c_int32, _P]),
     "cp_polydet_decode_workspace_bytes": (c_size_t, [c_int32] * 5),
     "cp_polydet_decode": (c_int32, [_P, _P, _P, _P] + [c_int32] * 7 + [_P, _P, _P, _P, c_size_t, _P]),

@@ -12,6 +12,8 @@ the reference.  No DCN here: every layer is a dense convolution.
 import torch
 import torch.nn as nn
 
+from .pose_dla_dcn import bn_act
+
 
 class convolution(nn.Module):
     def __init__(self, k, inp_dim, out_dim, stride=1, with_bn=True):
@@ -23,6 +25,8 @@ class convolution(nn.Module):
         self.relu = nn.ReLU(inplace=True)
 
     def forward(self, x):
+        if isinstance(self.bn, nn.BatchNorm2d):
+            return bn_act(self.bn, self.conv(x), relu=True)     # fused BN+ReLU in training
         return self.relu(self.bn(self.conv(x)))
 
 
@@ -42,9 +46,8 @@ class residual(nn.Module):
         self.relu = nn.ReLU(inplace=True)
 
     def forward(self, x):
-        y = self.relu1(self.bn1(self.conv1(x)))
-        y = self.bn2(self.conv2(y))
-        return self.relu(y + self.skip(x))
+        y = bn_act(self.bn1, self.conv1(x), relu=True)
+        return bn_act(self.bn2, self.conv2(y), relu=True, residual=self.skip(x))
 
 
 def _stack(first, rest_dim, count, tail=None):

@@ -67,6 +67,62 @@ def _conv_folded(x, conv, wb, relu=False, residual=None):
     return y
 
 
+# ---- training-time fused BatchNorm (+ residual) (+ ReLU) -------------------------------
+class _BnAct(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, residual, running_mean, running_var, momentum, eps, relu):
+        L = _C.lib()
+        x = x.contiguous()
+        res = residual.contiguous() if residual is not None else None
+        B, C, H, W = x.shape
+        y = torch.empty_like(x)
+        mean = torch.empty(C, dtype=torch.float32, device=x.device)
+        invstd = torch.empty(C, dtype=torch.float32, device=x.device)
+        ws = _C.workspace(L.cp_bn_workspace_bytes(B, C, H * W), x.device)
+        rc = L.cp_bn_act_forward_train(_C.ptr(x), _C.ptr(weight), _C.ptr(bias), _C.ptr(res), _C.ptr(y),
+                                       _C.ptr(mean), _C.ptr(invstd), _C.ptr(running_mean),
+                                       _C.ptr(running_var), momentum, eps, 1 if relu else 0, B, C,
+                                       H * W, _C.ptr(ws), ws.numel(), _C.stream())
+        _C.check(rc, "cp_bn_act_forward_train")
+        ctx.save_for_backward(x, y, weight, mean, invstd)
+        ctx.cfg = (relu, residual is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, y, weight, mean, invstd = ctx.saved_tensors
+        relu, has_res = ctx.cfg
+        L = _C.lib()
+        gy = gy.contiguous()
+        B, C, H, W = x.shape
+        gx = torch.empty_like(x)
+        gres = torch.empty_like(x) if has_res else None
+        gw = torch.zeros(C, dtype=torch.float32, device=x.device)
+        gb = torch.zeros(C, dtype=torch.float32, device=x.device)
+        ws = _C.workspace(L.cp_bn_workspace_bytes(B, C, H * W), x.device)
+        rc = L.cp_bn_act_backward(_C.ptr(x), _C.ptr(y), _C.ptr(gy), _C.ptr(weight), _C.ptr(mean),
+                                  _C.ptr(invstd), 1 if relu else 0, _C.ptr(gx), _C.ptr(gres), _C.ptr(gw),
+                                  _C.ptr(gb), B, C, H * W, _C.ptr(ws), ws.numel(), _C.stream())
+        _C.check(rc, "cp_bn_act_backward")
+        return gx, gw, gb, gres, None, None, None, None, None
+
+
+def bn_act(bn, x, relu=True, residual=None):
+    """relu(bn(x) + residual).  Training on a HIP device: one fused statistics pass + one fused
+    apply pass (and two passes backward) instead of BatchNorm, add and ReLU kernels; otherwise
+    the plain torch modules (eval mode normally takes the folded path before getting here)."""
+    if bn.training and x.is_cuda and x.dtype == torch.float32 and bn.track_running_stats \
+            and bn.affine and bn.momentum is not None and x.numel() // x.shape[1] > 1:
+        with torch.no_grad():
+            bn.num_batches_tracked += 1
+        return _BnAct.apply(x, bn.weight, bn.bias, residual, bn.running_mean, bn.running_var,
+                            float(bn.momentum), float(bn.eps), relu)
+    y = bn(x)
+    if residual is not None:
+        y = y + residual
+    return F.relu_(y) if relu else y
+
+
 class BasicBlock(nn.Module):
     def __init__(self, inplanes, planes, stride=1, dilation=1):
         super().__init__()
@@ -85,10 +141,8 @@ class BasicBlock(nn.Module):
         if _use_folded(self):
             y = _conv_folded(x, self.conv1, self._folded[0], relu=True)
             return _conv_folded(y, self.conv2, self._folded[1], relu=True, residual=skip)
-        y = self.relu(self.bn1(self.conv1(x)))
-        y = self.bn2(self.conv2(y))
-        y += skip
-        return self.relu(y)
+        y = bn_act(self.bn1, self.conv1(x), relu=True)
+        return bn_act(self.bn2, self.conv2(y), relu=True, residual=skip)
 
 
 class Root(nn.Module):
@@ -106,10 +160,8 @@ class Root(nn.Module):
         if _use_folded(self):
             return _conv_folded(torch.cat(xs, 1), self.conv, self._folded, relu=True,
                                 residual=xs[0] if self.residual else None)
-        y = self.bn(self.conv(torch.cat(xs, 1)))
-        if self.residual:
-            y += xs[0]
-        return self.relu(y)
+        return bn_act(self.bn, self.conv(torch.cat(xs, 1)), relu=True,
+                      residual=xs[0] if self.residual else None)
 
 
 class Tree(nn.Module):
@@ -212,6 +264,13 @@ class DLA(nn.Module):
                 if seq is not self.base_layer:
                     pyramid.append(x)
             first_tree = 2
+        elif self.training and x.is_cuda and all(len(q) == 3 for q in (self.base_layer, self.level0,
+                                                                        self.level1)):
+            for seq in (self.base_layer, self.level0, self.level1):
+                x = bn_act(seq[1], seq[0](x), relu=True)
+                if seq is not self.base_layer:
+                    pyramid.append(x)
+            first_tree = 2
         else:
             x = self.base_layer(x)
             first_tree = 0
@@ -275,6 +334,8 @@ class DeformConv(nn.Module):
             scale, shift = self._folded if getattr(self, "_folded", None) is not None \
                 else self.folded_affine()
             return self.conv.forward_fused(x, scale, shift, relu=True)
+        if self.training:
+            return bn_act(self.actf[0], self.conv(x), relu=True)
         return self.actf(self.conv(x))
 
 

@@ -143,6 +143,25 @@ int cp_depthwise_up_backward(const float* x, const float* weight, const float* g
 int cp_bias_act_inplace(float* y, const float* bias, const float* residual, int32_t B, int32_t C,
                         int64_t HW, int32_t relu, void* stream);
 
+/* --------------------------- fused training BatchNorm2d (+residual) (+ReLU) --
+ * y = act(bn(x) + residual) with batch statistics (torch.nn.BatchNorm2d training semantics:
+ * biased variance for normalisation, running stats updated with `momentum`, unbiased variance).
+ * Replaces the BN -> add -> ReLU chains of DeformConv / BasicBlock / Root / conv levels
+ * (src/lib/models/networks/pose_dla_dcn.py:32-60,148-166,266-277,347-359) in training.
+ * x, y, residual and their gradients: fp32 [B,C,H,W], HW = H x W; weight, bias, running and
+ * saved statistics: [C].  backward: grad_weight / grad_bias are ACCUMULATED INTO; grad_residual (may be NULL) receives
+ * the post-activation gradient; workspace from cp_bn_workspace_bytes. */
+size_t cp_bn_workspace_bytes(int32_t B, int32_t C, int64_t HW);
+int cp_bn_act_forward_train(const float* x, const float* weight, const float* bias,
+                            const float* residual, float* y, float* save_mean, float* save_invstd,
+                            float* running_mean, float* running_var, float momentum, float eps,
+                            int32_t relu, int32_t B, int32_t C, int64_t HW, void* workspace,
+                            size_t workspace_bytes, void* stream);
+int cp_bn_act_backward(const float* x, const float* y, const float* grad_y, const float* weight,
+                       const float* save_mean, const float* save_invstd, int32_t relu, float* grad_x,
+                       float* grad_residual, float* grad_weight, float* grad_bias, int32_t B,
+                       int32_t C, int64_t HW, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ----------------------------------------------------------------- decode --
  * heat [B,C,H,W] (already activated), polys [B,2N,H,W], depth [B,1,H,W],
  * reg [B,2,H,W] or NULL (then +0.5).  K <= 256.

@@ -521,6 +521,52 @@ def test_depthwise_up_add_backward_vs_autograd(f, C, H, W):
                                atol=1e-4 * wc.grad.abs().max().item())
 
 
+@pytest.mark.parametrize("shape,relu,with_res", [((2, 16, 12, 20), True, True), ((3, 5, 7, 9), True, False),
+                                                 ((2, 64, 64, 128), False, False), ((1, 8, 3, 5), True, True)])
+def test_fused_bn_act_vs_torch(shape, relu, with_res):
+    """Fused training BatchNorm (+residual)(+ReLU): outputs, running statistics and all gradients
+    against torch.nn.BatchNorm2d + add + relu on the CPU."""
+    from centerpoly_amd.models.networks.pose_dla_dcn import bn_act
+    C = shape[1]
+    x = synth.normal("bn/x%d" % C, shape, 0.3, 1.7)
+    res = synth.normal("bn/r%d" % C, shape) if with_res else None
+    gout = synth.normal("bn/g%d" % C, shape)
+
+    def make(dev):
+        bn = torch.nn.BatchNorm2d(C, momentum=0.1).to(dev).train()
+        with torch.no_grad():
+            bn.weight.copy_(T(synth.uniform("bn/w%d" % C, (C,), 0.5, 1.5)))
+            bn.bias.copy_(T(synth.normal("bn/b%d" % C, (C,))))
+            bn.running_mean.copy_(T(synth.normal("bn/rm%d" % C, (C,))))
+            bn.running_var.copy_(T(synth.uniform("bn/rv%d" % C, (C,), 0.5, 2.0)))
+        return bn
+
+    bc = make("cpu")
+    xc = T(x).requires_grad_(True)
+    rc = T(res).requires_grad_(True) if with_res else None
+    yc = bc(xc)
+    if with_res:
+        yc = yc + rc
+    if relu:
+        yc = torch.relu(yc)
+    yc.backward(T(gout))
+    bd = make(DEV)
+    xd = g(x).requires_grad_(True)
+    rd = g(res).requires_grad_(True) if with_res else None
+    yd = bn_act(bd, xd, relu=relu, residual=rd)
+    yd.backward(g(gout))
+    np.testing.assert_allclose(yd.detach().cpu().numpy(), yc.detach().numpy(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(bd.running_mean.cpu().numpy(), bc.running_mean.numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(bd.running_var.cpu().numpy(), bc.running_var.numpy(), rtol=1e-5, atol=1e-6)
+    assert int(bd.num_batches_tracked) == int(bc.num_batches_tracked) == 1
+    gs = xc.grad.abs().max().item()
+    np.testing.assert_allclose(xd.grad.cpu().numpy(), xc.grad.numpy(), rtol=1e-3, atol=1e-5 * max(gs, 1.0))
+    np.testing.assert_allclose(bd.weight.grad.cpu().numpy(), bc.weight.grad.numpy(), rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(bd.bias.grad.cpu().numpy(), bc.bias.grad.numpy(), rtol=1e-4, atol=1e-4)
+    if with_res:
+        np.testing.assert_allclose(rd.grad.cpu().numpy(), rc.grad.numpy(), rtol=0, atol=0)
+
+
 def test_folded_conv_epilogue_matches_bn_relu():
     """BasicBlock in eval mode: folded conv + fused bias/residual/ReLU pass == conv, BN, add, ReLU."""
     from centerpoly_amd.models.networks.pose_dla_dcn import BasicBlock
