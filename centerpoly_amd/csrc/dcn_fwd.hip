@@ -26,6 +26,17 @@ namespace {
 
 constexpr int BM = 64;       // pixels per workgroup
 constexpr int TAPS = 9;      // 3x3 only in this kernel
+// LDS row stride of the column / weight tiles = k extent + LDPAD dwords.  The MFMA fragment reads
+// (lane = (row r, k = q)) hit bank (LD*r + q) mod 32 inside each 32-lane group: LD = 2*odd makes
+// LD*r cover the 16 even banks, so the reads are conflict-free (an odd LD leaves three 2-way
+// conflicts per read = 2x the LDS cycles; PMC: 44 % of LDS cycles were conflicts).  The lane =
+// pixel stores become 2-way conflicted, which a ds_write_b32 absorbs at no cost.
+#ifndef CP_DCN_LDPAD
+#define CP_DCN_LDPAD 2
+#endif
+constexpr int LDPAD = CP_DCN_LDPAD;
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 struct DcnFwdArgs {
   const float* x;
@@ -53,12 +64,67 @@ struct DcnFwdArgs {
 #else
 #define CP_ABL(bit) 0
 #endif
+// compile-time mask for the interleaved kernel (a runtime flag would change its schedule)
+#ifdef CP_ABLATE_MASK
+#define CP_ABLP(bit) ((CP_ABLATE_MASK) & (bit))
+#else
+#define CP_ABLP(bit) 0
+#endif
+
+// Per-pixel sampling recipe shared by the fp32 kernels (W >= 2).
+// Per tap: the two x-neighbours of a row are ONE 8-byte gather.  The pair starts at
+// xl = clamp(x0, 0, W-2) so both dwords are always inside the plane; the corner weights move
+// to the slot their column landed in (x0 = -1 -> the valid right corner sits in the low slot,
+// x0 = W-1 -> the valid left corner sits in the high slot).  Half the vector-memory
+// instructions of the 4-dword form (the gather stream is what bounds this kernel) and 18
+// fewer address registers.
+__device__ __forceinline__ void pair_recipe(const DcnFwdArgs& a, int b, int p, bool p_ok,
+                                            float (&cw)[TAPS][4], unsigned (&coff)[TAPS][2]) {
+  const int HWo = a.Ho * a.Wo;
+  const int ho = p_ok ? p / a.Wo : 0;
+  const int wo = p_ok ? p - ho * a.Wo : 0;
+  const float* off = a.offset + (long long)b * a.offset_bstride;
+  const float* msk = a.mask + (long long)b * a.mask_bstride;
+  float oy[TAPS], ox[TAPS], mk[TAPS];
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t) {
+    oy[t] = p_ok ? off[(long long)(2 * t) * HWo + p] : 0.f;
+    ox[t] = p_ok ? off[(long long)(2 * t + 1) * HWo + p] : 0.f;
+    mk[t] = p_ok ? msk[(long long)t * HWo + p] : 0.f;
+  }
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t) {
+    const int ky = t / 3, kx = t - ky * 3;
+    float m = mk[t];
+    if (a.mask_is_logit) m = 1.f / (1.f + __expf(-m));
+    const float py = (float)(ho * a.stride - a.pad + ky * a.dil) + oy[t];
+    const float px = (float)(wo * a.stride - a.pad + kx * a.dil) + ox[t];
+    const bool inside = p_ok && py > -1.f && px > -1.f && py < (float)a.H && px < (float)a.W;
+    const float fy = floorf(py), fx = floorf(px);
+    const int y0 = (int)fy, x0 = (int)fx;
+    const float ly = py - fy, lx = px - fx;
+    const float hy = 1.f - ly, hx = 1.f - lx;
+    const bool y0ok = y0 >= 0, y1ok = y0 + 1 <= a.H - 1;
+    const int y0c = min(max(y0, 0), a.H - 1), y1c = min(max(y0 + 1, 0), a.H - 1);
+    const int xl = min(max(x0, 0), a.W - 2);
+    // column weights of the pair's low / high dword (columns xl and xl + 1)
+    const float wlo = (x0 == xl) ? hx : ((x0 + 1 == xl) ? lx : 0.f);
+    const float whi = (x0 == xl) ? lx : ((x0 == xl + 1) ? hx : 0.f);
+    const float wy0 = (inside && y0ok) ? hy : 0.f, wy1 = (inside && y1ok) ? ly : 0.f;
+    cw[t][0] = wy0 * wlo * m;
+    cw[t][1] = wy0 * whi * m;
+    cw[t][2] = wy1 * wlo * m;
+    cw[t][3] = wy1 * whi * m;
+    coff[t][0] = inside ? 4u * (unsigned)(y0c * a.W + xl) : 0u;
+    coff[t][1] = inside ? 4u * (unsigned)(y1c * a.W + xl) : 0u;
+  }
+}
 
 template <int BN, int KC, int WPS>
 __global__ __launch_bounds__(256, WPS) void dcn_fwd_kernel(DcnFwdArgs a) {
   static_assert(sizeof(int) == 4, "");
   constexpr int KK = KC * TAPS;          // k extent of one chunk
-  constexpr int LD = KK + 1;             // odd row stride (dwords)
+  constexpr int LD = KK + LDPAD;         // row stride (dwords), see LDPAD
   constexpr int NT = BN / 32;            // 16-wide n tiles per wave
   constexpr int CPW = KC / 4;            // channels sampled per wave per chunk
   static_assert(KK % 4 == 0, "chunk must be a multiple of the MFMA k");
@@ -76,52 +142,14 @@ __global__ __launch_bounds__(256, WPS) void dcn_fwd_kernel(DcnFwdArgs a) {
   const int p = blockIdx.x * BM + lane;
   const bool p_ok = p < HWo;
 
-  // ---- per-pixel sampling recipes, kept in registers ----
-  // cw[t][0..3]: corner weights x mask x validity; coff[t][0..3]: BYTE offsets of the four
-  // (clamped) corners inside one channel plane.  Gathers are raw buffer loads: wave-uniform
-  // resource descriptor (SGPRs) + this 32-bit per-lane offset + the channel's plane offset in
-  // the scalar soffset operand -- no per-gather 64-bit VALU address arithmetic (PMC showed the
-  // flat-address form issue-bound: 6.7 VALU per MFMA), and out-of-range reads return 0.
+  // ---- per-pixel sampling recipes, kept in registers: 4 corner weights x mask x validity and
+  // the byte offsets of the two row pairs inside one channel plane.  Gathers are raw buffer
+  // loads: wave-uniform resource descriptor (SGPRs) + this 32-bit per-lane offset + the
+  // channel's plane offset in the scalar soffset operand -- no per-gather 64-bit VALU address
+  // arithmetic (PMC showed the flat-address form issue-bound: 6.7 VALU per MFMA).
   float cw[TAPS][4];
-  unsigned coff[TAPS][4];
-  {
-    const int ho = p_ok ? p / a.Wo : 0;
-    const int wo = p_ok ? p - ho * a.Wo : 0;
-    const float* off = a.offset + (long long)b * a.offset_bstride;
-    const float* msk = a.mask + (long long)b * a.mask_bstride;
-    float oy[TAPS], ox[TAPS], mk[TAPS];
-#pragma unroll
-    for (int t = 0; t < TAPS; ++t) {
-      oy[t] = (p_ok && !CP_ABL(16)) ? off[(long long)(2 * t) * HWo + p] : 0.f;
-      ox[t] = (p_ok && !CP_ABL(16)) ? off[(long long)(2 * t + 1) * HWo + p] : 0.f;
-      mk[t] = (p_ok && !CP_ABL(16)) ? msk[(long long)t * HWo + p] : 0.f;
-    }
-#pragma unroll
-    for (int t = 0; t < TAPS; ++t) {
-      const int ky = t / 3, kx = t - ky * 3;
-      float m = mk[t];
-      if (a.mask_is_logit) m = 1.f / (1.f + __expf(-m));
-      const float py = (float)(ho * a.stride - a.pad + ky * a.dil) + oy[t];
-      const float px = (float)(wo * a.stride - a.pad + kx * a.dil) + ox[t];
-      const bool inside = p_ok && py > -1.f && px > -1.f && py < (float)a.H && px < (float)a.W;
-      const float fy = floorf(py), fx = floorf(px);
-      const int y0 = (int)fy, x0 = (int)fx;
-      const float ly = py - fy, lx = px - fx;
-      const float hy = 1.f - ly, hx = 1.f - lx;
-      const bool y0ok = y0 >= 0, y1ok = y0 + 1 <= a.H - 1;
-      const bool x0ok = x0 >= 0, x1ok = x0 + 1 <= a.W - 1;
-      const int y0c = min(max(y0, 0), a.H - 1), y1c = min(max(y0 + 1, 0), a.H - 1);
-      const int x0c = min(max(x0, 0), a.W - 1), x1c = min(max(x0 + 1, 0), a.W - 1);
-      cw[t][0] = (inside && y0ok && x0ok) ? hy * hx * m : 0.f;
-      cw[t][1] = (inside && y0ok && x1ok) ? hy * lx * m : 0.f;
-      cw[t][2] = (inside && y1ok && x0ok) ? ly * hx * m : 0.f;
-      cw[t][3] = (inside && y1ok && x1ok) ? ly * lx * m : 0.f;
-      coff[t][0] = inside ? 4u * (unsigned)(y0c * a.W + x0c) : 0u;
-      coff[t][1] = inside ? 4u * (unsigned)(y0c * a.W + x1c) : 0u;
-      coff[t][2] = inside ? 4u * (unsigned)(y1c * a.W + x0c) : 0u;
-      coff[t][3] = inside ? 4u * (unsigned)(y1c * a.W + x1c) : 0u;
-    }
-  }
+  unsigned coff[TAPS][2];
+  pair_recipe(a, b, p, p_ok, cw, coff);
 
   f32x4 acc[2][NT];
 #pragma unroll
@@ -184,8 +212,11 @@ __global__ __launch_bounds__(256, WPS) void dcn_fwd_kernel(DcnFwdArgs a) {
           continue;
         }
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
-          g[cc][t][k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_x, coff[t][k], xsoff, 0));
+        for (int k = 0; k < 2; ++k) {
+          const f32x2 v = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_x, coff[t][k], xsoff, 0));
+          g[cc][t][2 * k] = v.x;
+          g[cc][t][2 * k + 1] = v.y;
+        }
       }
     }
   };
@@ -280,7 +311,7 @@ template <int BN, int WPS>
 __global__ __launch_bounds__(256, WPS) void dcn_fwd_pipe_kernel(DcnFwdArgs a) {
   constexpr int KC = 4;
   constexpr int KK = KC * TAPS;          // 36
-  constexpr int LD = KK + 1;             // 37
+  constexpr int LD = KK + LDPAD;         // 38
   constexpr int NT = BN / 32;
   constexpr int WPT = BN * KK / 256;     // weight elements per thread per chunk (9 / 18)
   constexpr int WPK = WPT / TAPS;        // ... per k-step (1 / 2)
@@ -295,46 +326,9 @@ __global__ __launch_bounds__(256, WPS) void dcn_fwd_pipe_kernel(DcnFwdArgs a) {
   const int p = blockIdx.x * BM + lane;
   const bool p_ok = p < HWo;
 
-  float cw[TAPS][4];
-  unsigned coff[TAPS][4];
-  {
-    const int ho = p_ok ? p / a.Wo : 0;
-    const int wo = p_ok ? p - ho * a.Wo : 0;
-    const float* off = a.offset + (long long)b * a.offset_bstride;
-    const float* msk = a.mask + (long long)b * a.mask_bstride;
-    float oy[TAPS], ox[TAPS], mk[TAPS];
-#pragma unroll
-    for (int t = 0; t < TAPS; ++t) {
-      oy[t] = p_ok ? off[(long long)(2 * t) * HWo + p] : 0.f;
-      ox[t] = p_ok ? off[(long long)(2 * t + 1) * HWo + p] : 0.f;
-      mk[t] = p_ok ? msk[(long long)t * HWo + p] : 0.f;
-    }
-#pragma unroll
-    for (int t = 0; t < TAPS; ++t) {
-      const int ky = t / 3, kx = t - ky * 3;
-      float m = mk[t];
-      if (a.mask_is_logit) m = 1.f / (1.f + __expf(-m));
-      const float py = (float)(ho * a.stride - a.pad + ky * a.dil) + oy[t];
-      const float px = (float)(wo * a.stride - a.pad + kx * a.dil) + ox[t];
-      const bool inside = p_ok && py > -1.f && px > -1.f && py < (float)a.H && px < (float)a.W;
-      const float fy = floorf(py), fx = floorf(px);
-      const int y0 = (int)fy, x0 = (int)fx;
-      const float ly = py - fy, lx = px - fx;
-      const float hy = 1.f - ly, hx = 1.f - lx;
-      const bool y0ok = y0 >= 0, y1ok = y0 + 1 <= a.H - 1;
-      const bool x0ok = x0 >= 0, x1ok = x0 + 1 <= a.W - 1;
-      const int y0c = min(max(y0, 0), a.H - 1), y1c = min(max(y0 + 1, 0), a.H - 1);
-      const int x0c = min(max(x0, 0), a.W - 1), x1c = min(max(x0 + 1, 0), a.W - 1);
-      cw[t][0] = (inside && y0ok && x0ok) ? hy * hx * m : 0.f;
-      cw[t][1] = (inside && y0ok && x1ok) ? hy * lx * m : 0.f;
-      cw[t][2] = (inside && y1ok && x0ok) ? ly * hx * m : 0.f;
-      cw[t][3] = (inside && y1ok && x1ok) ? ly * lx * m : 0.f;
-      coff[t][0] = inside ? 4u * (unsigned)(y0c * a.W + x0c) : 0u;
-      coff[t][1] = inside ? 4u * (unsigned)(y0c * a.W + x1c) : 0u;
-      coff[t][2] = inside ? 4u * (unsigned)(y1c * a.W + x0c) : 0u;
-      coff[t][3] = inside ? 4u * (unsigned)(y1c * a.W + x1c) : 0u;
-    }
-  }
+  float cw[TAPS][4];                          // {row0 lo, row0 hi, row1 lo, row1 hi}
+  unsigned coff[TAPS][2];                     // byte offsets of the two row pairs
+  pair_recipe(a, b, p, p_ok, cw, coff);
 
   f32x4 acc[2][NT];
 #pragma unroll
@@ -373,17 +367,29 @@ __global__ __launch_bounds__(256, WPS) void dcn_fwd_pipe_kernel(DcnFwdArgs a) {
     // (foreign samples are zeroed in build_tap) and carry the chunk's k offset in voffset
     const unsigned xsoff = (unsigned)min(c0 + swid, a.Cin - 1) * plane_bytes;
 #pragma unroll
-    for (int k = 0; k < 4; ++k)
-      g[t][k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_x, coff[t][k], xsoff, 0));
+    for (int k = 0; k < 2; ++k) {
+      if (CP_ABLP(1)) {
+        g[t][2 * k] = g[t][2 * k + 1] = 1.f;
+      } else {
+        // (bit_cast of the whole vector: a bit_cast of the element expression `v.y` reads v.x)
+        const f32x2 v = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_x, coff[t][k], xsoff, 0));
+        g[t][2 * k] = v.x;
+        g[t][2 * k + 1] = v.y;
+      }
+    }
     const unsigned wk = (unsigned)(c0 * TAPS) * 4u;
 #pragma unroll
     for (int q = 0; q < WPK; ++q) {
-      wreg[t * WPK + q] = __builtin_bit_cast(
+      wreg[t * WPK + q] = CP_ABLP(4) ? 1.f : __builtin_bit_cast(
           float, __builtin_amdgcn_raw_buffer_load_b32(rs_w, woff[t * WPK + q] + wk, 0, 0));
     }
   };
   auto build_tap = [&](float* buf, int c0, int t) {   // tap t of chunk c0 -> LDS buffer `buf`
     const float v = cw[t][0] * g[t][0] + cw[t][1] * g[t][1] + cw[t][2] * g[t][2] + cw[t][3] * g[t][3];
+    if (CP_ABLP(2)) {
+      if (v == 12345.f) buf[0] = v + wreg[t * WPK];
+      return;
+    }
     buf[colw + t] = (c0 + swid < c_end) ? v : 0.f;     // split-K: foreign channels contribute 0
 #pragma unroll
     for (int q = 0; q < WPK; ++q) buf[wlds[t * WPK + q]] = wreg[t * WPK + q];
@@ -409,14 +415,18 @@ __global__ __launch_bounds__(256, WPS) void dcn_fwd_pipe_kernel(DcnFwdArgs a) {
     for (int t = 0; t < TAPS; ++t) {             // k-step t of chunk c0  ||  tap t of chunk c0+KC
       float af[2], bf[NT];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) af[i] = cur[arow + i * 16 * LD + t * 4];
+      for (int i = 0; i < 2; ++i) af[i] = CP_ABLP(32) ? cw[t][i] : cur[arow + i * 16 * LD + t * 4];
 #pragma unroll
-      for (int j = 0; j < NT; ++j) bf[j] = cur[brow + j * 16 * LD + t * 4];
+      for (int j = 0; j < NT; ++j) bf[j] = CP_ABLP(32) ? cw[t][2 + (j & 1)] : cur[brow + j * 16 * LD + t * 4];
+      if (!CP_ABLP(8)) {
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < NT; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < NT; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+      } else {
+        acc[0][0][0] += af[0] + af[1] + bf[0] + bf[NT - 1];
+      }
       build_tap(nxt, c0 + KC, t);
       load_tap(c0 + 2 * KC, t);
       // keep hipcc from sinking the re-issued gathers to the loop bottom (it did: the next
@@ -713,11 +723,13 @@ struct Plan {
 };
 
 Plan make_plan(int B, int Cin, int Cout, int HWo) {
-  // Widest N tile that is not mostly padding: every extra N tile re-samples the
-  // columns.  Under-filled grids are topped up by splitting K, not by narrowing N.
+  // Widest N tile (up to 128) that is not mostly padding: every extra N tile re-samples the
+  // columns.  Under-filled grids are topped up by splitting K, not by narrowing N.  (A 256-wide
+  // tile samples once but only fits the phase-separated kernel at one wave per SIMD: measured
+  // 0.170 vs 0.109 ms on 256->256 @64x128, so Cout > 128 takes two 128-wide tiles.)
   const long long tiles_m = (long long)((HWo + BM - 1) / BM) * B;
   Plan p;
-  p.bn = Cout > 128 ? 256 : (Cout > 64 ? 128 : 64);
+  p.bn = Cout > 64 ? 128 : 64;
   const long long blocks = tiles_m * ((Cout + p.bn - 1) / p.bn);
   p.splitk = 1;
   const int kc = 4;
@@ -738,7 +750,7 @@ Plan make_plan(int B, int Cin, int Cout, int HWo) {
 
 template <int BN, int KC, int WPS>
 int launch(const DcnFwdArgs& a, hipStream_t st) {
-  constexpr int LD = KC * TAPS + 1;
+  constexpr int LD = KC * TAPS + LDPAD;
   const size_t lds = (size_t)(BM + BN) * LD * sizeof(float);
   dim3 grid((a.Ho * a.Wo + BM - 1) / BM, (a.Cout + BN - 1) / BN, a.B * a.splitk);
   hipLaunchKernelGGL((dcn_fwd_kernel<BN, KC, WPS>), grid, dim3(256), lds, st, a);
@@ -753,7 +765,7 @@ int launch(const DcnFwdArgs& a, hipStream_t st) {
 
 template <int BN, int WPS>
 int launch_pipe(const DcnFwdArgs& a, hipStream_t st) {
-  const size_t lds = (size_t)2 * (BM + BN) * 37 * sizeof(float);
+  const size_t lds = (size_t)2 * (BM + BN) * (4 * TAPS + LDPAD) * sizeof(float);
   if (lds > 64 * 1024)
     (void)hipFuncSetAttribute((const void*)dcn_fwd_pipe_kernel<BN, WPS>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -816,6 +828,7 @@ extern "C" int cp_dcn_v2_forward(const cp_dcn_shape* s, const float* x, const fl
   const int Wo = out_extent(s->W, s->pad, s->dil, s->stride);
   CP_CHECK_ARG(Ho > 0 && Wo > 0);
   if ((long long)s->H * s->W >= (1ll << 31) || (long long)Ho * Wo >= (1ll << 31)) return CP_EUNSUPPORTED;
+  if (s->W < 2) return CP_EUNSUPPORTED;          // the x-pair gathers need two columns
   const Plan p = make_plan(s->B, s->Cin, s->Cout, Ho * Wo);
   if ((long long)s->B * p.splitk > 65535) return CP_EUNSUPPORTED;
   if (p.splitk > 1) {
@@ -847,6 +860,5 @@ extern "C" int cp_dcn_v2_forward(const cp_dcn_shape* s, const float* x, const fl
     if (p.bn == 128) return launch_pipe<128, 2>(a, st);
   }
   if (p.bn == 64) return launch<64, 4, 2>(a, st);
-  if (p.bn == 128) return launch<128, 4, 1>(a, st);
-  return launch<256, 4, 1>(a, st);
+  return launch<128, 4, 1>(a, st);
 }
