@@ -4,8 +4,9 @@
   N = 1 (default)  one step = one 2048x1024 image through DLA-34 + DCNv2 -> sigmoid -> fused
                    NMS/top-k/decode (BASELINE config 2); `value` = inference img/s.  The same
                    line carries the 1-GPU training point (`train`), the DCNv2 forward roofline
-                   measured with HIP events inside the timed region (`roofline`,
-                   `roofline_mfma`) and the CPU oracle timed on a bounded sample
+                   measured with HIP events inside the timed region (`roofline` against the
+                   fp32 matrix pipe that bounds it, `roofline_hbm` for the same launch against
+                   HBM) and the CPU oracle timed on a bounded sample
                    (`cpu_baseline`).
   N > 1            one step = one data-parallel training step (BASELINE config 3: DLA-34 + DCNv2,
                    4 images of 2048x1024 per GPU, 16-vertex cartesian head, l1+iou polygon loss,
@@ -153,7 +154,8 @@ def dcn_roofline(summary):
            "algorithmic_bytes_per_launch": alg_bytes}
     mfma = {"bound": "mfma", "achieved": alg_flops / avg_s / 1e12, "peak": MFMA_F32_PEAK_TF,
             "unit": "TFLOP/s", "frac": alg_flops / avg_s / 1e12 / MFMA_F32_PEAK_TF, "traffic": traffic,
-            "kernel": layer, "algorithmic_flops_per_launch": alg_flops}
+            "kernel": layer, "algorithmic_flops_per_launch": alg_flops,
+            "avg_launch_us": avg_s * 1e6, "launches": summary[key]["launches"]}
     return hbm, mfma
 
 
@@ -234,12 +236,17 @@ def main():
                                    "cartesian head, K=128, forward + sigmoid + NMS/top-k/decode"
                                    % (args.height, args.width),
                        "images_per_step": world, "parallelism": "replicas" if world > 1 else "single"},
-            "roofline": hbm, "roofline_mfma": mfma,
+            # the dominant kernel's arithmetic intensity (119 FLOP/B) is 6x the fp32 ridge point
+            # (157.3 TFLOP/s / 8 TB/s = 19.7 FLOP/B): the fp32 matrix pipe is the binding roofline,
+            # the HBM fraction of the same launch is reported beside it
+            "roofline": mfma, "roofline_hbm": hbm,
             "dcn_layers_ms": {"%d->%d@%dx%d" % k[1:]: round(v["avg_ms"], 4) for k, v in summary.items()},
         })
         if world == 1 and not args.no_train_point:
             tt = train_leg(args, dev, 1, 0, args.train_steps, 2)
-            line["train"] = {"metric": "train img/s", "value": args.train_batch * args.train_steps / tt,
+            # same workload per GPU as the N > 1 lines: the 1-GPU point of the training scaling curve
+            line["train"] = {"metric": "train img/s 1/2/4/8 GPU @2048x1024 DLA-34",
+                             "value": args.train_batch * args.train_steps / tt,
                              "ms_per_step": 1e3 * tt / args.train_steps, "n_gpus": 1,
                              "global_batch": args.train_batch, "steps": args.train_steps,
                              "workload": "BASELINE config 3 per-GPU share: DLA-34 + DCNv2, %d x 3x%dx%d, "
@@ -255,6 +262,9 @@ def main():
                        "global_batch": world * args.train_batch,
                        "parallelism": "dp%d (one process per GPU, RCCL all-reduce)" % world},
             "roofline": None,
+            "scaling_base": "weak scaling of the training leg: compare with the N=1 line's "
+                            "train.value (same %d img/GPU workload), not with its inference value"
+                            % args.train_batch,
         })
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:

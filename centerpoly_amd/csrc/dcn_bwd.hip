@@ -274,7 +274,6 @@ constexpr int RH = 2 * RR + 2;           // 8 rows
 constexpr int RW = BM + 2 * RR + 1;      // 71 columns
 constexpr int RWP = 72;                  // padded row
 constexpr int RSZ = RH * RWP;            // 576 floats per channel
-constexpr int RPT = (KC * RSZ + 255) / 256;   // region elements per thread (9)
 
 template <int CP, int WPS>                // Cout rounded up to 64/128/256; waves per SIMD
 __global__ __launch_bounds__(256, WPS) void dcn_bwd_data_tiled_kernel(DcnBwdArgs a) {

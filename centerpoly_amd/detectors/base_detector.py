@@ -3,10 +3,11 @@
 Same surface: BaseDetector(opt); .pre_process(image, scale, meta) -> (images, meta);
 .run(image_or_path_or_tensor) -> {'results', 'tot','load','pre','net','dec','post','merge'}.
 The accelerated path is GPU-only: opt.gpus = [-1] raises instead of silently
-running on the host.  cv2 is not required: the affine warp of pre_process is a
-numpy bilinear inverse map (zero border), a .npy path or ndarray is accepted as
-the image source, and `opt.load_model == ''` keeps the random initialisation
-(the reference calls torch.load unconditionally, :27).
+running on the host.  cv2 is not required: the 8-bit image is uploaded as is and
+the affine warp + normalisation of pre_process run in one HIP kernel with OpenCV's
+fixed-point arithmetic (cp_preprocess_warp_normalize), a .npy path or ndarray is
+accepted as the image source, and `opt.load_model == ''` keeps the random
+initialisation (the reference calls torch.load unconditionally, :27).
 """
 import time
 
@@ -14,38 +15,15 @@ import numpy as np
 import torch
 
 from ..models.model import create_model, load_model
-from ..utils.image import get_affine_transform
+from ..utils.image import get_affine_transform, warp_affine_normalize
 
 
-def _resize_bilinear(img, new_w, new_h):
-    h, w = img.shape[:2]
-    if (w, h) == (new_w, new_h):
-        return img
-    t = torch.from_numpy(np.ascontiguousarray(img)).permute(2, 0, 1)[None].float()
+def _resize_bilinear_u8(img_dev, new_w, new_h):
+    """cv2.resize stand-in for --test_scales != 1 (device, bilinear, result rounded back to 8 bits;
+    OpenCV's fixed-point resize can differ from it by one grey level)."""
+    t = img_dev.permute(2, 0, 1)[None].float()
     t = torch.nn.functional.interpolate(t, size=(new_h, new_w), mode="bilinear", align_corners=False)
-    return t[0].permute(1, 2, 0).numpy()
-
-
-def _warp_affine(img, trans, out_w, out_h):
-    """dst(x,y) = src(M^-1 [x,y,1]) with bilinear taps and zero border."""
-    M = np.vstack([trans, [0, 0, 1]])
-    Minv = np.linalg.inv(M)[:2]
-    xs, ys = np.meshgrid(np.arange(out_w, dtype=np.float64), np.arange(out_h, dtype=np.float64))
-    sx = Minv[0, 0] * xs + Minv[0, 1] * ys + Minv[0, 2]
-    sy = Minv[1, 0] * xs + Minv[1, 1] * ys + Minv[1, 2]
-    x0, y0 = np.floor(sx).astype(np.int64), np.floor(sy).astype(np.int64)
-    fx, fy = (sx - x0)[..., None], (sy - y0)[..., None]
-    h, w = img.shape[:2]
-    src = img.astype(np.float32)
-
-    def tap(yy, xx):
-        ok = (yy >= 0) & (yy < h) & (xx >= 0) & (xx < w)
-        v = src[np.clip(yy, 0, h - 1), np.clip(xx, 0, w - 1)]
-        return v * ok[..., None]
-
-    out = (1 - fy) * ((1 - fx) * tap(y0, x0) + fx * tap(y0, x0 + 1)) \
-        + fy * ((1 - fx) * tap(y0 + 1, x0) + fx * tap(y0 + 1, x0 + 1))
-    return out.astype(np.float32)
+    return t[0].permute(1, 2, 0).round_().clamp_(0, 255).to(torch.uint8).contiguous()
 
 
 class BaseDetector(object):
@@ -83,16 +61,25 @@ class BaseDetector(object):
             c = np.array([new_width // 2, new_height // 2], dtype=np.float32)
             s = np.array([inp_width, inp_height], dtype=np.float32)
         trans_input = get_affine_transform(c, s, 0, [inp_width, inp_height])
-        resized = _resize_bilinear(image, new_width, new_height)
-        inp = _warp_affine(resized, trans_input, inp_width, inp_height)
-        inp = ((inp / 255.0 - self.mean) / self.std).astype(np.float32)
-        images = inp.transpose(2, 0, 1).reshape(1, 3, inp_height, inp_width)
-        if self.opt.flip_test:
-            images = np.concatenate((images, images[:, :, :, ::-1]), axis=0)
-        images = torch.from_numpy(np.ascontiguousarray(images))
+        src = self._upload(image)
+        if (new_height, new_width) != (height, width):
+            src = _resize_bilinear_u8(src, new_width, new_height)
+        images = warp_affine_normalize(src, trans_input, self.mean, self.std, inp_height, inp_width,
+                                       flip_copy=bool(self.opt.flip_test))
         meta = {"c": c, "s": s, "out_height": inp_height // self.opt.down_ratio,
                 "out_width": inp_width // self.opt.down_ratio}
         return images, meta
+
+    def _upload(self, image):
+        """8-bit HWC image -> device through a cached pinned staging buffer."""
+        if image.dtype != np.uint8 or image.ndim != 3 or image.shape[2] != 3:
+            raise TypeError("pre_process needs an 8-bit [H,W,3] image (got %s %s)"
+                            % (image.dtype, image.shape))
+        pin = getattr(self, "_pin", None)
+        if pin is None or tuple(pin.shape) != tuple(image.shape):
+            pin = self._pin = torch.empty(image.shape, dtype=torch.uint8).pin_memory()
+        pin.copy_(torch.from_numpy(np.ascontiguousarray(image)))
+        return pin.to(self.opt.device, non_blocking=True)
 
     def process(self, images, return_time=False):
         raise NotImplementedError

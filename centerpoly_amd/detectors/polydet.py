@@ -6,7 +6,7 @@ import torch
 
 from ..models.decode import polydet_decode
 from ..models.utils import flip_tensor
-from ..utils.post_process import polydet_post_process
+from ..utils.post_process import polydet_post_process_device
 from .base_detector import BaseDetector
 
 
@@ -35,24 +35,10 @@ class PolydetDetector(BaseDetector):
         return output, dets
 
     def post_process(self, dets, meta, scale=1, fg=None):
-        dets = dets.detach().cpu().numpy()
-        dets = dets.reshape(1, -1, dets.shape[2])
-        dets = polydet_post_process(dets.copy(), [meta["c"]], [meta["s"]], meta["out_height"],
-                                    meta["out_width"], self.opt.num_classes)
-        for j in range(1, self.num_classes + 1):
-            rows = dets[0][j]
-            n_cols = len(rows[0]) if rows else 0
-            a = np.array(rows, dtype=np.float32).reshape(-1, n_cols) if rows else \
-                np.zeros((0, 0), dtype=np.float32)
-            if a.size:
-                a[:, :4] /= scale
-                a[:, 5:-1] /= scale
-            dets[0][j] = a
-        ncol = max((d.shape[1] for d in dets[0].values() if d.size), default=0)
-        for j in dets[0]:
-            if dets[0][j].size == 0:
-                dets[0][j] = np.zeros((0, ncol), dtype=np.float32)
-        return dets[0]
+        # transform_preds + `/ scale` on the device, one copy back, class split on the host
+        dets = dets.detach().reshape(1, -1, dets.shape[2])
+        return polydet_post_process_device(dets, [meta["c"]], [meta["s"]], meta["out_height"],
+                                           meta["out_width"], self.opt.num_classes, scale)[0]
 
     def merge_outputs(self, detections):
         if len(self.scales) > 1 or self.opt.nms:

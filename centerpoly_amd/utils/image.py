@@ -4,6 +4,8 @@
 float64); `transform_preds` is vectorised over rows instead of a Python loop that
 recomputes the transform per call site.
 """
+import ctypes
+
 import numpy as np
 
 
@@ -65,3 +67,25 @@ def transform_preds(coords, center, scale, output_size):
     target = np.zeros(coords.shape)
     target[:, 0:2] = apply_affine(coords, get_affine_transform(center, scale, 0, output_size, inv=1))
     return target
+
+
+def warp_affine_normalize(image_u8, trans, mean, std, dst_h, dst_w, flip_copy=False):
+    """cv2.warpAffine(INTER_LINEAR, constant border 0) of an 8-bit HWC image followed by
+    ((x / 255. - mean) / std) and HWC -> CHW, on the device (reference:
+    src/lib/detectors/base_detector.py:66-87).  image_u8: uint8 [H,W,3] HIP tensor; trans: the
+    forward 2x3 map (float64); returns fp32 [1 + flip_copy, 3, dst_h, dst_w] on the same device."""
+    import torch
+
+    from .. import _C
+    if image_u8.dtype != torch.uint8 or image_u8.dim() != 3 or image_u8.shape[2] != 3:
+        raise TypeError("warp_affine_normalize needs a uint8 [H,W,3] image tensor")
+    t = (ctypes.c_double * 6)(*[float(v) for v in np.asarray(trans, dtype=np.float64).ravel()])
+    m = (ctypes.c_float * 3)(*[float(v) for v in np.asarray(mean, dtype=np.float32).ravel()])
+    sd = (ctypes.c_float * 3)(*[float(v) for v in np.asarray(std, dtype=np.float32).ravel()])
+    out = torch.empty((2 if flip_copy else 1, 3, int(dst_h), int(dst_w)), dtype=torch.float32,
+                      device=image_u8.device)
+    _C.check(_C.lib().cp_preprocess_warp_normalize(
+        _C.ptr(image_u8), image_u8.shape[0], image_u8.shape[1], ctypes.cast(t, ctypes.c_void_p),
+        ctypes.cast(m, ctypes.c_void_p), ctypes.cast(sd, ctypes.c_void_p), int(dst_h), int(dst_w),
+        1 if flip_copy else 0, _C.ptr(out), _C.stream()), "cp_preprocess_warp_normalize")
+    return out

@@ -143,6 +143,29 @@ int cp_depthwise_up_backward(const float* x, const float* weight, const float* g
 int cp_bias_act_inplace(float* y, const float* bias, const float* residual, int32_t B, int32_t C,
                         int64_t HW, int32_t relu, void* stream);
 
+/* ------------------------------------------------ detector pre/post-processing --
+ * cp_preprocess_warp_normalize: the cv2 stage of BaseDetector.pre_process
+ * (src/lib/detectors/base_detector.py:66-87): cv2.warpAffine(image, trans_input, (dst_w, dst_h),
+ * flags=INTER_LINEAR) on the 8-bit image followed by ((x / 255. - mean) / std) and the HWC -> CHW
+ * transpose; OpenCV's fixed-point arithmetic, bit-identical to oracle/pre.py.
+ *   src   DEVICE uint8 [src_h][src_w][3]      trans  HOST float64[6], forward map src -> dst
+ *   mean, std  HOST float32[3]                out    DEVICE fp32 [1 + flip_copy][3][dst_h][dst_w]
+ * flip_copy != 0 also writes the horizontally flipped image behind it (--flip_test, :84-85).
+ *
+ * cp_polydet_post_process: transform_preds of polydet_post_process
+ * (src/lib/utils/post_process.py:105-122, src/lib/utils/image.py:19-24) + the `/ scale` of
+ * PolydetDetector.post_process (src/lib/detectors/polydet.py:52-57) on the decoded rows
+ *   dets [B][K][ncols] (ncols = 2N + 7: x1,y1,x2,y2,score,class, N vertices, depth), DEVICE
+ *   trans_dev  DEVICE float64 [B][6]: inverse affine (output map -> image) per image
+ * Box corners and vertices are mapped in float64, cast to fp32, divided by `scale`; the other
+ * columns are copied.  out has the layout of dets (out == dets is NOT allowed). */
+int cp_preprocess_warp_normalize(const uint8_t* src, int32_t src_h, int32_t src_w,
+                                 const double* trans, const float* mean, const float* stdv,
+                                 int32_t dst_h, int32_t dst_w, int32_t flip_copy, float* out,
+                                 void* stream);
+int cp_polydet_post_process(const float* dets, const double* trans_dev, float scale, int32_t B,
+                            int32_t K, int32_t ncols, float* out, void* stream);
+
 /* --------------------------- fused training BatchNorm2d (+residual) (+ReLU) --
  * y = act(bn(x) + residual) with batch statistics (torch.nn.BatchNorm2d training semantics:
  * biased variance for normalisation, running stats updated with `momentum`, unbiased variance).

@@ -1,0 +1,150 @@
+"""Detector pre/post-processing: the OpenCV restatement (oracle/pre.py, CPU) and the HIP
+kernels behind cp_preprocess_warp_normalize / cp_polydet_post_process (GPU, bit-exact /
+1e-6 against the oracle).  cv2 is not installed: oracle/pre.py is pinned only by the
+closed-form cases below (identity, integer translation, exact half-pixel averages)."""
+import numpy as np
+import pytest
+import torch
+
+from centerpoly_amd import synth
+from oracle import post as opost
+from oracle import pre as opre
+
+MEAN = np.array([0.284, 0.323, 0.282], dtype=np.float32)
+STD = np.array([0.04, 0.04, 0.04], dtype=np.float32)
+
+
+def _img(tag, h, w):
+    return (synth.uniform("pre/" + tag, (h, w, 3)) * 256).astype(np.uint8)
+
+
+def _affines():
+    th = 0.3
+    return {
+        "identity": (np.array([[1, 0, 0], [0, 1, 0]], np.float64), (96, 64)),
+        "shift": (np.array([[1, 0, 16], [0, 1, -5]], np.float64), (128, 80)),
+        "half": (np.array([[0.5, 0, 0], [0, 0.5, 0]], np.float64), (48, 32)),
+        "fixres": (opost.get_affine_transform(np.array([48., 32.], np.float32), 96.0, 0, [64, 32]), (64, 32)),
+        "rot": (np.array([[1.3 * np.cos(th), -1.3 * np.sin(th), 7.25], [1.3 * np.sin(th), 1.3 * np.cos(th), -11.5]]),
+                (150, 90)),
+        "frac": (np.array([[0.77, 0.02, 3.4], [-0.03, 0.81, 2.6]], np.float64), (100, 70)),
+    }
+
+
+# ------------------------------------------------------------------- CPU ---
+
+def test_warp_identity_and_integer_shift_are_exact_copies():
+    img = _img("a", 64, 96)
+    M, ds = _affines()["identity"]
+    assert np.array_equal(opre.warp_affine_u8(img, M, ds), img)
+    M, (dw, dh) = _affines()["shift"]
+    out = opre.warp_affine_u8(img, M, (dw, dh))
+    ref = np.zeros((dh, dw, 3), np.uint8)
+    ref[0:59, 16:112] = img[5:64, 0:96]            # dst(x, y) = src(x - 16, y + 5)
+    assert np.array_equal(out, ref)
+
+
+def test_warp_downscale_by_two_reads_exact_pixels():
+    # dst(x, y) = src(2x, 2y): integer source coordinates, weights 0 / 2^15
+    img = _img("b", 64, 96)
+    M, ds = _affines()["half"]
+    assert np.array_equal(opre.warp_affine_u8(img, M, ds), img[::2, ::2])
+
+
+def test_warp_half_pixel_is_rounded_average():
+    img = _img("c", 8, 8)
+    M = np.array([[1, 0, -0.5], [0, 1, 0]], np.float64)        # dst(x) = src(x + 0.5)
+    out = opre.warp_affine_u8(img, M, (7, 8)).astype(np.int64)
+    a, b = img[:, :7].astype(np.int64), img[:, 1:8].astype(np.int64)
+    assert np.array_equal(out, (a * 16384 + b * 16384 + 16384) >> 15)
+
+
+@pytest.mark.parametrize("name", ["fixres", "rot", "frac"])
+def test_warp_fixed_point_tracks_float_bilinear(name):
+    img = _img("d", 64, 96)
+    M, (dw, dh) = _affines()[name]
+    out = opre.warp_affine_u8(img, M, (dw, dh)).astype(np.float64)
+    Mi = opre.invert_affine(M)
+    xs, ys = np.meshgrid(np.arange(dw, dtype=np.float64), np.arange(dh, dtype=np.float64))
+    sx = Mi[0, 0] * xs + Mi[0, 1] * ys + Mi[0, 2]
+    sy = Mi[1, 0] * xs + Mi[1, 1] * ys + Mi[1, 2]
+    x0, y0 = np.floor(sx).astype(int), np.floor(sy).astype(int)
+    fx, fy = (sx - x0)[..., None], (sy - y0)[..., None]
+
+    def tap(yy, xx):
+        ok = (yy >= 0) & (yy < 64) & (xx >= 0) & (xx < 96)
+        return img[np.clip(yy, 0, 63), np.clip(xx, 0, 95)].astype(np.float64) * ok[..., None]
+
+    ref = (1 - fy) * ((1 - fx) * tap(y0, x0) + fx * tap(y0, x0 + 1)) + fy * ((1 - fx) * tap(y0 + 1, x0) + fx * tap(y0 + 1, x0 + 1))
+    # 1/32-pixel coordinate quantisation: a few grey levels on white-noise content, none on average
+    assert np.abs(out - ref).max() <= 12.0 and abs((out - ref).mean()) < 0.2
+
+
+def test_pre_process_keep_res_is_a_centred_copy():
+    img = _img("e", 60, 100)
+    images, meta, trans = opre.pre_process(img, 1, MEAN, STD, flip_test=True)
+    assert images.shape == (2, 3, 64, 128) and images.dtype == np.float32
+    assert meta["out_height"] == 16 and meta["out_width"] == 32
+    ref = np.zeros((64, 128, 3), np.uint8)
+    ref[2:62, 14:114] = img
+    exp = ((ref / 255. - MEAN.reshape(1, 1, 3)) / STD.reshape(1, 1, 3)).astype(np.float32).transpose(2, 0, 1)
+    assert np.array_equal(images[0], exp)
+    assert np.array_equal(images[1], exp[:, :, ::-1])
+
+
+# ------------------------------------------------------------------- GPU ---
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(_affines()))
+@pytest.mark.parametrize("flip", [False, True])
+def test_preprocess_kernel_bit_exact_vs_oracle(name, flip):
+    from centerpoly_amd.utils.image import warp_affine_normalize
+    img = _img("g" + name, 64, 96)
+    M, (dw, dh) = _affines()[name]
+    ref = opre.normalize_chw(opre.warp_affine_u8(img, M, (dw, dh)), MEAN, STD)
+    out = warp_affine_normalize(torch.from_numpy(img).cuda(), M, MEAN, STD, dh, dw, flip_copy=flip).cpu().numpy()
+    assert out.shape == (2 if flip else 1, 3, dh, dw)
+    assert np.array_equal(out[0], ref)
+    if flip:
+        assert np.array_equal(out[1], ref[:, :, ::-1])
+
+
+@pytest.mark.gpu
+def test_preprocess_full_size_keep_res_and_fix_res():
+    from centerpoly_amd.utils.image import warp_affine_normalize
+    img = _img("full", 1024, 2048)
+    dev = torch.from_numpy(img).cuda()
+    for kw in ({}, {"fix_res": True, "input_h": 512, "input_w": 1024}):
+        ref, meta, trans = opre.pre_process(img, 1, MEAN, STD, **kw)
+        out = warp_affine_normalize(dev, trans, MEAN, STD, ref.shape[2], ref.shape[3]).cpu().numpy()
+        assert np.array_equal(out, ref)
+
+
+@pytest.mark.gpu
+def test_preprocess_rejects_bad_arguments():
+    from centerpoly_amd import _C
+    from centerpoly_amd.utils.image import warp_affine_normalize
+    with pytest.raises(TypeError):
+        warp_affine_normalize(torch.zeros(8, 8, 3, device="cuda"), np.eye(2, 3), MEAN, STD, 8, 8)
+    with pytest.raises(_C.NativeError):
+        warp_affine_normalize(torch.zeros(8, 8, 3, dtype=torch.uint8), np.eye(2, 3), MEAN, STD, 8, 8)
+    with pytest.raises(_C.NativeError):
+        warp_affine_normalize(torch.zeros(8, 8, 3, dtype=torch.uint8, device="cuda"), np.eye(2, 3), MEAN, STD, 0, 8)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,scale", [(16, 1.0), (32, 0.5), (24, 2.0)])
+def test_post_process_kernel_vs_oracle(N, scale):
+    from centerpoly_amd.utils.post_process import polydet_post_process_device
+    K, ncols = 128, 2 * N + 7
+    d = synth.uniform("post/d%d" % N, (1, K, ncols), 0.0, 500.0).astype(np.float32)
+    d[0, :, 4] = synth.uniform("post/s%d" % N, (K,))
+    d[0, :, 5] = synth.integers("post/c%d" % N, (K,), 0, 8).astype(np.float32)
+    meta = {"c": np.array([1024., 512.], np.float32), "s": np.array([2080., 1056.], np.float32),
+            "out_height": 264, "out_width": 520}
+    ref = opost.detector_post_process(d.copy(), meta, scale, 8)
+    out = polydet_post_process_device(torch.from_numpy(d).cuda(), [meta["c"]], [meta["s"]], 264, 520, 8, scale)[0]
+    assert sorted(out) == list(range(1, 9))
+    for j in range(1, 9):
+        assert out[j].shape == ref[j].shape and out[j].dtype == np.float32
+        np.testing.assert_allclose(out[j], ref[j], rtol=1e-6, atol=1e-4)
