@@ -55,6 +55,8 @@ def parse():
     p.add_argument("--dcn_contraction", default="f32", choices=["f32", "bf16x3"],
                    help="DCNv2 forward contraction at inference: exact fp32 MFMA or split-bf16 x3")
     p.add_argument("--no_cpu_baseline", action="store_true")
+    p.add_argument("--no_detector_point", action="store_true",
+                   help="skip the end-to-end PolydetDetector.run point of the N=1 line")
     p.add_argument("--no_train_point", action="store_true")
     return p.parse_args()
 
@@ -186,6 +188,39 @@ def train_leg(args, dev, world, rank, steps, warmup):
     return t
 
 
+def detector_leg(args, dev):
+    """End-to-end PolydetDetector.run on a host uint8 image (upload over PCIe, device warp +
+    normalise, network, decode, device affine post-process, copy back, per-class dicts)."""
+    from centerpoly_amd import synth
+    from centerpoly_amd.detectors.detector_factory import detector_factory
+    from centerpoly_amd.opts import opts
+    import numpy as np
+    with contextlib.redirect_stdout(sys.stderr):
+        opt = opts().init(["polydet", "--arch", "dla_34", "--input_h", str(args.height),
+                           "--input_w", str(args.width)])
+        det = detector_factory["polydet"](opt)
+    img = (synth.uniform("bench/detector/img", (args.height, args.width, 3)) * 255).astype(np.uint8)
+    for _ in range(3):
+        det.run(img)
+    n = 20
+    keys = ["pre", "net", "dec", "post", "merge"]
+    acc = dict.fromkeys(keys, 0.0)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        ret = det.run(img)
+        for k in keys:
+            acc[k] += ret[k]
+    t = time.perf_counter() - t0
+    del det
+    torch.cuda.empty_cache()
+    return {"metric": "PolydetDetector.run img/s (host uint8 image in, result dicts out, PCIe included)",
+            "value": n / t, "ms_per_image": 1e3 * t / n,
+            "stage_ms": {k: round(1e3 * v / n, 3) for k, v in acc.items()},
+            "workload": "%dx%d uint8 image, keep_res (network input %dx%d), K=%d"
+                        % (args.width, args.height, (args.width | 31) + 1, (args.height | 31) + 1, opt.K)}
+
+
 def cpu_baseline(args):
     """The CPU oracle (a port of the reference's path) on a bounded sample: ONE full-size
     image through DLA-34 + DCNv2 + decode (a few seconds on a 16-core host share)."""
@@ -242,6 +277,9 @@ def main():
             "roofline": mfma, "roofline_hbm": hbm,
             "dcn_layers_ms": {"%d->%d@%dx%d" % k[1:]: round(v["avg_ms"], 4) for k, v in summary.items()},
         })
+        if world == 1 and not args.no_detector_point:
+            line["detector_end_to_end"] = detector_leg(args, dev)
+            note("detector end-to-end point done")
         if world == 1 and not args.no_train_point:
             tt = train_leg(args, dev, 1, 0, args.train_steps, 2)
             # same workload per GPU as the N > 1 lines: the 1-GPU point of the training scaling curve

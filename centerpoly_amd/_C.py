@@ -54,6 +54,7 @@ _SIGNATURES = {
     "cp_bias_act_inplace": (c_int32, [_P, _P, _P, c_int32, c_int32, c_int64, c_int32, _P]),
     "cp_preprocess_warp_normalize": (c_int32, [_P, c_int32, c_int32, _P, _P, _P, c_int32, c_int32, c_int32, _P, _P]),
     "cp_polydet_post_process": (c_int32, [_P, _P, c_float, c_int32, c_int32, c_int32, _P, _P]),
+    "cp_soft_nms": (c_int32, [_P, c_int32, c_int32, c_float, c_float, c_float, c_int32]),
     "cp_polydet_decode_workspace_bytes": (c_size_t, [c_int32] * 5),
     "cp_polydet_decode": (c_int32, [_P, _P, _P, _P] + [c_int32] * 7 + [_P, _P, _P, _P, c_size_t, _P]),
     "cp_sigmoid_focal_workspace_bytes": (c_size_t, [c_int64]),

@@ -4,6 +4,7 @@ import time
 import numpy as np
 import torch
 
+from ..external.nms import soft_nms
 from ..models.decode import polydet_decode
 from ..models.utils import flip_tensor
 from ..utils.post_process import polydet_post_process_device
@@ -41,12 +42,11 @@ class PolydetDetector(BaseDetector):
                                            meta["out_width"], self.opt.num_classes, scale)[0]
 
     def merge_outputs(self, detections):
-        if len(self.scales) > 1 or self.opt.nms:
-            raise NotImplementedError("soft-nms / multi-scale merging (external/nms.pyx) is a "
-                                      "'next' row, not in the accelerated path yet")
         results = {}
         for j in range(1, self.num_classes + 1):
             results[j] = np.concatenate([d[j] for d in detections], axis=0).astype(np.float32)
+            if len(self.scales) > 1 or self.opt.nms:
+                soft_nms(results[j], Nt=0.5, method=2)
         scores = np.hstack([results[j][:, 4] for j in range(1, self.num_classes + 1)])
         if len(scores) > self.max_per_image:
             kth = len(scores) - self.max_per_image

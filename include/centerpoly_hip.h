@@ -166,6 +166,13 @@ int cp_preprocess_warp_normalize(const uint8_t* src, int32_t src_h, int32_t src_
 int cp_polydet_post_process(const float* dets, const double* trans_dev, float scale, int32_t B,
                             int32_t K, int32_t ncols, float* out, void* stream);
 
+/* soft_nms of external/nms.pyx:77-170 (Cython in the reference) on HOST float32 rows
+ * [n][row_stride] (x1,y1,x2,y2,score,...), in place, as merge_outputs uses it
+ * (src/lib/detectors/polydet.py:66-67: Nt=0.5, method=2).  method 0 hard / 1 linear /
+ * 2 gaussian.  Only columns 0-4 move; returns the live row count N (>= 0) or CP_EINVAL. */
+int cp_soft_nms(float* boxes_host, int32_t n, int32_t row_stride, float sigma, float Nt,
+                float threshold, int32_t method);
+
 /* --------------------------- fused training BatchNorm2d (+residual) (+ReLU) --
  * y = act(bn(x) + residual) with batch statistics (torch.nn.BatchNorm2d training semantics:
  * biased variance for normalisation, running stats updated with `momentum`, unbiased variance).

@@ -5,6 +5,11 @@ src/lib/utils/image.py:19-66 (transform_preds / get_affine_transform /
 affine_transform) and src/lib/detectors/polydet.py:45-76.
 `cv2.getAffineTransform` (image.py:56,58) is the exact affine through three
 point pairs; restated as a 6x6 linear solve in float64.
+
+soft_nms follows src/lib/external/nms.pyx:77-170 (Cython, `cdef float` arithmetic emulated
+with numpy float32 scalars).  PARITY OF soft_nms IS UNPINNED: the reference's nms.pyx does not
+compile against this image's numpy 2.2 / Cython 3.2 (`np.int_t`, `np.float` no longer exist),
+so it could not be built into oracle/_ref, and the reference holds no fixture for it.
 """
 import numpy as np
 
@@ -91,11 +96,59 @@ def detector_post_process(dets, meta, scale, num_classes):
     return out[0]
 
 
-def merge_outputs(detections, num_classes, max_per_image):
-    """detectors/polydet.py:62-76 without soft-nms (single scale, --nms off)."""
+def soft_nms(boxes, sigma=0.5, Nt=0.3, threshold=0.001, method=0):
+    """external/nms.pyx:77-170, IN PLACE on float32 [n, >= 5] rows (x1,y1,x2,y2,score,...).
+    Literal behaviour: only columns 0-4 are swapped / overwritten (the polygon columns of a
+    row stay where they were), rows are never removed from the array (N shrinks internally),
+    and the caller in detectors/polydet.py:66-67 ignores the returned keep list."""
+    f = np.float32
+    one = f(1)
+    sigma, Nt, threshold = f(sigma), f(Nt), f(threshold)
+    N0 = N = boxes.shape[0]
+    for i in range(N0):                      # range(N) is evaluated once (i is a Python object)
+        maxscore, maxpos = boxes[i, 4], i
+        t = boxes[i, 0:5].copy()
+        pos = i + 1
+        while pos < N:
+            if maxscore < boxes[pos, 4]:
+                maxscore, maxpos = boxes[pos, 4], pos
+            pos += 1
+        boxes[i, 0:5] = boxes[maxpos, 0:5]
+        boxes[maxpos, 0:5] = t
+        tx1, ty1, tx2, ty2 = boxes[i, 0], boxes[i, 1], boxes[i, 2], boxes[i, 3]
+        pos = i + 1
+        while pos < N:
+            x1, y1, x2, y2 = boxes[pos, 0], boxes[pos, 1], boxes[pos, 2], boxes[pos, 3]
+            area = (x2 - x1 + one) * (y2 - y1 + one)
+            iw = min(tx2, x2) - max(tx1, x1) + one
+            if iw > 0:
+                ih = min(ty2, y2) - max(ty1, y1) + one
+                if ih > 0:
+                    ua = (tx2 - tx1 + one) * (ty2 - ty1 + one) + area - iw * ih
+                    ov = iw * ih / ua
+                    if method == 1:
+                        weight = one - ov if ov > Nt else one
+                    elif method == 2:
+                        weight = f(np.exp(np.float64(-(ov * ov) / sigma)))
+                    else:
+                        weight = f(0) if ov > Nt else one
+                    boxes[pos, 4] = weight * boxes[pos, 4]
+                    if boxes[pos, 4] < threshold:
+                        boxes[pos, 0:5] = boxes[N - 1, 0:5]
+                        N -= 1
+                        pos -= 1
+            pos += 1
+    return list(range(N))
+
+
+def merge_outputs(detections, num_classes, max_per_image, nms=False):
+    """detectors/polydet.py:62-76; soft-nms (Nt=0.5, gaussian) when several scales were run
+    or --nms is set (`nms=True`)."""
     results = {}
     for j in range(1, num_classes + 1):
         results[j] = np.concatenate([d[j] for d in detections], axis=0).astype(np.float32)
+        if nms:
+            soft_nms(results[j], Nt=0.5, method=2)
     scores = np.hstack([results[j][:, 4] for j in range(1, num_classes + 1)])
     if len(scores) > max_per_image:
         kth = len(scores) - max_per_image

@@ -148,3 +148,91 @@ def test_post_process_kernel_vs_oracle(N, scale):
     for j in range(1, 9):
         assert out[j].shape == ref[j].shape and out[j].dtype == np.float32
         np.testing.assert_allclose(out[j], ref[j], rtol=1e-6, atol=1e-4)
+
+
+# ---------------------------------------------------------------- soft_nms ---
+# Host code of the C ABI (cp_soft_nms): runs without a GPU.
+
+def _boxes(tag, n, ncols=38, spread=200.0):
+    c = synth.uniform("nms/c" + tag, (n, 2), 0.0, spread)
+    wh = synth.uniform("nms/wh" + tag, (n, 2), 5.0, 80.0)
+    b = synth.uniform("nms/rest" + tag, (n, ncols), 0.0, 300.0).astype(np.float32)
+    b[:, 0:2] = c - wh / 2
+    b[:, 2:4] = c + wh / 2
+    b[:, 4] = synth.uniform("nms/s" + tag, (n,), 0.0, 1.0)
+    return b.astype(np.float32)
+
+
+@pytest.mark.parametrize("method", [0, 1, 2])
+@pytest.mark.parametrize("n,spread", [(1, 50.0), (40, 60.0), (256, 400.0), (300, 40.0)])
+def test_soft_nms_c_matches_oracle_bitwise(method, n, spread):
+    from centerpoly_amd.external.nms import soft_nms
+    a = _boxes("%d-%d" % (n, method), n, spread=spread)
+    b = a.copy()
+    keep_ref = opost.soft_nms(a, sigma=0.5, Nt=0.5, threshold=0.001 if n < 300 else 0.2, method=method)
+    keep = soft_nms(b, sigma=0.5, Nt=0.5, threshold=0.001 if n < 300 else 0.2, method=method)
+    assert keep == keep_ref
+    assert np.array_equal(a, b)
+
+
+def test_soft_nms_known_answers():
+    from centerpoly_amd.external.nms import soft_nms
+    # two identical boxes: the second keeps exp(-1 / sigma) of its score (gaussian), polygon columns untouched
+    b = np.array([[0, 0, 9, 9, 0.5, 7, 7], [0, 0, 9, 9, 0.9, 8, 8], [100, 100, 109, 109, 0.7, 9, 9]], np.float32)
+    keep = soft_nms(b, sigma=0.5, Nt=0.5, method=2)
+    assert keep == [0, 1, 2]
+    np.testing.assert_array_equal(b[:, 5:], [[7, 7], [8, 8], [9, 9]])          # columns >= 5 never move
+    np.testing.assert_allclose(b[:, 4], [0.9, 0.7, np.float32(0.5) * np.float32(np.exp(-2.0))], rtol=1e-7)
+    # hard NMS: the overlapped box is discarded (overwritten by the last live row), length unchanged
+    b = np.array([[0, 0, 9, 9, 0.9], [1, 1, 10, 10, 0.8], [50, 50, 59, 59, 0.7]], np.float32)
+    assert soft_nms(b, Nt=0.3, method=0) == [0, 1]
+    np.testing.assert_array_equal(b[:2], np.array([[0, 0, 9, 9, 0.9], [50, 50, 59, 59, 0.7]], np.float32))
+    assert soft_nms(np.zeros((0, 38), np.float32)) == []
+    with pytest.raises(TypeError):
+        soft_nms(np.zeros((4, 38), np.float64))
+
+
+def test_merge_outputs_with_soft_nms_matches_oracle():
+    from centerpoly_amd.detectors.polydet import PolydetDetector
+    det = PolydetDetector.__new__(PolydetDetector)           # merge_outputs only needs these fields
+    det.num_classes, det.max_per_image, det.scales = 8, 100, [0.5, 1.0]
+    det.opt = type("O", (), {"nms": False})()
+    dets = [{j: _boxes("m%d-%d" % (s, j), 10 + j, spread=80.0) for j in range(1, 9)} for s in range(2)]
+    ref = opost.merge_outputs([{j: v.copy() for j, v in d.items()} for d in dets], 8, 100, nms=True)
+    out = det.merge_outputs([{j: v.copy() for j, v in d.items()} for d in dets])
+    for j in range(1, 9):
+        assert np.array_equal(out[j], ref[j])
+    assert sum(len(v) for v in out.values()) <= 100 + 8
+
+
+@pytest.mark.gpu
+def test_detector_multiscale_flip_nms_vs_oracle_pipeline():
+    """--test_scales 1,0.5 --flip_test: PolydetDetector.run against the oracle's decode /
+    post-process / soft-nms merge driven with the same head outputs."""
+    from centerpoly_amd.detectors.detector_factory import detector_factory
+    from centerpoly_amd.models.utils import flip_tensor
+    from centerpoly_amd.opts import opts
+    from oracle import decode as odec
+    opt = opts().init(["polydet", "--arch", "smallhourglass", "--test_scales", "1,0.5", "--flip_test", "--K", "32"])
+    torch.manual_seed(317)
+    det = detector_factory["polydet"](opt)
+    img = (synth.uniform("ms/img", (192, 256, 3)) * 255).astype(np.uint8)
+    ret = det.run(img)
+    res = ret["results"]
+    assert sorted(res) == list(range(1, 9))
+    per_scale = []
+    for scale in opt.test_scales:
+        images, meta = det.pre_process(img, scale)
+        assert images.shape[0] == 2 and images.is_cuda
+        assert torch.equal(images[1], images[0].flip(-1))
+        with torch.no_grad():
+            out = det.model(images)[-1]
+            hm = out["hm"].sigmoid()
+            hm = ((hm[0:1] + flip_tensor(hm[1:2])) / 2).cpu()
+        dref, _, _ = odec.polydet_decode(hm, out["poly"][0:1].cpu(), out["pseudo_depth"][0:1].cpu(),
+                                         out["reg"][0:1].cpu(), K=opt.K, rep="cartesian")
+        per_scale.append(opost.detector_post_process(dref.numpy(), meta, scale, 8))
+    ref = opost.merge_outputs(per_scale, 8, opt.K, nms=True)
+    for j in range(1, 9):
+        assert res[j].shape == ref[j].shape
+        np.testing.assert_allclose(res[j], ref[j], rtol=1e-4, atol=2e-3)
