@@ -23,6 +23,11 @@ class DcnShape(Structure):
                                        "dil", "deformable_groups")]
 
 
+class TargetShape(Structure):
+    _fields_ = [(n, c_int32) for n in ("B", "max_objs", "nbr_points", "num_classes", "out_h", "out_w",
+                                       "rep", "no_reorder_flip")]
+
+
 class NativeLibraryMissing(ImportError):
     pass
 
@@ -54,6 +59,8 @@ _SIGNATURES = {
     "cp_bias_act_inplace": (c_int32, [_P, _P, _P, c_int32, c_int32, c_int64, c_int32, _P]),
     "cp_preprocess_warp_normalize": (c_int32, [_P, c_int32, c_int32, _P, _P, _P, c_int32, c_int32, c_int32, _P, _P]),
     "cp_polydet_post_process": (c_int32, [_P, _P, c_float, c_int32, c_int32, c_int32, _P, _P]),
+    "cp_polydet_targets_workspace_bytes": (c_size_t, [POINTER(TargetShape)]),
+    "cp_polydet_targets": (c_int32, [POINTER(TargetShape)] + [_P] * 19 + [_P, c_size_t, _P]),
     "cp_soft_nms": (c_int32, [_P, c_int32, c_int32, c_float, c_float, c_float, c_int32]),
     "cp_polydet_decode_workspace_bytes": (c_size_t, [c_int32] * 5),
     "cp_polydet_decode": (c_int32, [_P, _P, _P, _P] + [c_int32] * 7 + [_P, _P, _P, _P, c_size_t, _P]),

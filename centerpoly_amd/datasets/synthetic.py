@@ -22,8 +22,38 @@ class SyntheticPolydet(data.Dataset):
     def __len__(self):
         return self.num_samples
 
+    def _raw_item(self, index):
+        """--device_targets: raw annotations + the crop/flip of the reference's sampler
+        (sample/polydet.py:88-130), packed for cp_polydet_targets; no target arithmetic here."""
+        from ..utils.image import get_affine_transform
+        from .sample.polydet import pack_annotations
+        opt = self.opt
+        tag = "%s/raw/%d" % (self.split, index)
+        img_h, img_w = opt.input_h, opt.input_w
+        anns = synth.raw_annotations(tag, img_h, img_w, nbr_points=opt.nbr_points, num_classes=self.num_classes)
+        c = np.array([img_w / 2.0, img_h / 2.0], dtype=np.float32)
+        s = max(img_h, img_w) * 1.0
+        flipped = False
+        if self.split == "train":
+            u = synth.uniform(tag + "/aug", (4,))
+            s = s * float(np.arange(0.6, 1.4, 0.1)[int(u[0] * 8) % 8])
+            c[0] = np.float32(int(img_w * (0.25 + 0.5 * u[1])))
+            c[1] = np.float32(int(img_h * (0.25 + 0.5 * u[2])))
+            if u[3] < 0.5:
+                flipped = True
+                c[0] = img_w - c[0] - 1
+        h, w = opt.input_h // opt.down_ratio, opt.input_w // opt.down_ratio
+        item = pack_annotations(anns, get_affine_transform(c, s, 0, [w, h]), flipped, img_w,
+                                self.max_objs, opt.nbr_points)
+        item["input"] = synth.normal(tag + "/input", (3, opt.input_h, opt.input_w))
+        if self.split != "train":
+            item["meta"] = {"c": c, "s": np.float32(s), "img_id": index, "out_height": h, "out_width": w}
+        return item
+
     def __getitem__(self, index):
         opt = self.opt
+        if getattr(opt, "device_targets", False):
+            return self._raw_item(index)
         h, w = opt.input_h // opt.down_ratio, opt.input_w // opt.down_ratio
         b = synth.train_batch(1, h, w, nbr_points=opt.nbr_points, num_classes=self.num_classes,
                               max_objs=self.max_objs, rep=opt.rep,

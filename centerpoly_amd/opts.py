@@ -55,6 +55,10 @@ class opts(object):
                        help="where exp/<dataset>/<task>/<exp_id> is created (reference: hard-coded ../)")
         p.add_argument("--synthetic_samples", type=int, default=64,
                        help="items per epoch of the synthetic dataset")
+        p.add_argument("--device_targets", action="store_true",
+                       help="loader workers only pack the raw annotations; heat maps and regression "
+                            "targets are built on the GPU (cp_polydet_targets) after the batch upload")
+        p.add_argument("--no_reorder_flip", action="store_true")
         p.add_argument("--bucket_cap_mb", type=int, default=32,
                        help="gradient all-reduce bucket size (RCCL over xGMI)")
         # test

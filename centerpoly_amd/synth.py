@@ -170,3 +170,32 @@ def train_batch(B, h, w, nbr_points=16, num_classes=8, max_objs=128, rep="cartes
     out.update(hm=hm, reg_mask=reg_mask, ind=ind, reg=reg, pseudo_depth=depth, poly=poly,
                freq_mask=np.ones((B,), dtype=np.float32), peak=peak)
     return out
+
+
+def raw_annotations(stream, in_h, in_w, nbr_points=16, num_classes=8, n_objs=None, seed=SEED):
+    """One image's RAW polydet annotations in image coordinates -- what the reference's sampler
+    reads from the COCO json (src/lib/datasets/sample/polydet.py:160-170) before it builds the
+    targets: a list of {bbox: [x, y, w, h], poly: [2N], cls_id, pseudo_depth, freq}.  Polygons
+    are star shaped around a centre, vertices ordered by increasing angle starting near the
+    top-left like the GT files; some objects hang over the image border and a few are tiny."""
+    N = nbr_points
+    if n_objs is None:
+        n_objs = int(integers(stream + "/n", (1,), 1, 41, seed)[0])
+    ctr = uniform(stream + "/ctr", (n_objs, 2), 0.0, 1.0, seed, dtype=np.float64)
+    rad = uniform(stream + "/rad", (n_objs, N), 6.0, 180.0, seed, dtype=np.float64)
+    size = uniform(stream + "/size", (n_objs,), 0.02, 1.0, seed, dtype=np.float64)
+    cls = integers(stream + "/cls", (n_objs,), 0, num_classes, seed)
+    depth = uniform(stream + "/depth", (n_objs,), 0.0, 1.0, seed)
+    freq = uniform(stream + "/freq", (num_classes,), 0.05, 1.0, seed)
+    anns = []
+    for k in range(n_objs):
+        cx, cy = ctr[k, 0] * in_w, ctr[k, 1] * in_h
+        theta = -0.75 * np.pi + np.arange(N) * (2 * np.pi / N)
+        xs = np.round(cx + size[k] * rad[k] * np.cos(theta), 2)
+        ys = np.round(cy + size[k] * rad[k] * np.sin(theta), 2)
+        pts = np.stack([xs, ys], axis=1).reshape(-1)
+        x0, y0, x1, y1 = xs.min(), ys.min(), xs.max(), ys.max()
+        anns.append({"bbox": [float(x0), float(y0), float(x1 - x0), float(y1 - y0)],
+                     "poly": [float(v) for v in pts], "cls_id": int(cls[k]),
+                     "pseudo_depth": float(depth[k]), "freq": float(freq[cls[k]])})
+    return anns

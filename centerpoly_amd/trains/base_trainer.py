@@ -83,6 +83,7 @@ class BaseTrainer(object):
             for k in batch:
                 if k != "meta":
                     batch[k] = batch[k].to(device=opt.device, non_blocking=True)
+            batch = self.prepare_batch(batch)
             with torch.set_grad_enabled(train):
                 output, loss, loss_stats = self.step(batch, train)
             batch_time.update(time.time() - end)
@@ -100,6 +101,10 @@ class BaseTrainer(object):
         ret = {k: v.avg for k, v in avg.items()}
         ret["time"] = (time.time() - t0) / 60.0
         return ret, results
+
+    def prepare_batch(self, batch):
+        """Hook between the batch upload and the step (device-side target construction)."""
+        return batch
 
     def debug(self, batch, output, iter_id):
         raise NotImplementedError

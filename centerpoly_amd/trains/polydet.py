@@ -80,6 +80,22 @@ class PolydetTrainer(BaseTrainer):
             loss_states = ["loss", "hm_l", "off_l", "poly_l", "depth_l"]
         return loss_states, PolydetLoss(opt)
 
+    def prepare_batch(self, batch):
+        """--device_targets: the loader delivered packed raw annotations (bbox, poly, cls_id, ...,
+        trans_output); build hm / ind / reg / poly / ... on the GPU (the reference does this per
+        object in the sampler, src/lib/datasets/sample/polydet.py:160-405)."""
+        if "trans_output" not in batch:
+            return batch
+        from ..datasets.sample.polydet import build_targets
+        opt = self.opt
+        h, w = batch["input"].shape[2] // opt.down_ratio, batch["input"].shape[3] // opt.down_ratio
+        targets = build_targets(batch, h, w, opt.num_classes, rep=opt.rep,
+                                no_reorder_flip=getattr(opt, "no_reorder_flip", False),
+                                with_border_hm=False)
+        out = {k: v for k, v in batch.items() if k in ("input", "meta")}
+        out.update(targets)
+        return out
+
     def debug(self, batch, output, iter_id):
         raise NotImplementedError("the reference's debug() reads output['wh'], which polydet "
                                   "never produces (trains/polydet.py:185-188)")

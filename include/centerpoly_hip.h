@@ -173,6 +173,30 @@ int cp_polydet_post_process(const float* dets, const double* trans_dev, float sc
 int cp_soft_nms(float* boxes_host, int32_t n, int32_t row_stride, float sigma, float Nt,
                 float threshold, int32_t method);
 
+/* ------------------------------------------------- training-target construction --
+ * The per-object loop of PolydetDataset.__getitem__ (src/lib/datasets/sample/polydet.py:160-405)
+ * with affine_transform / gaussian_radius / draw_umich_gaussian (src/lib/utils/image.py:62-65,
+ * 95-141): raw annotations of a batch -> the tensors of the batch dict (:425-449).
+ * Inputs (all DEVICE): bbox_xywh f64 [B][M][4] COCO boxes, poly_xy f64 [B][M][2N] vertices in
+ * image coordinates, cls_id i32 [B][M], pseudo_depth_in f32 [B][M], class_freq f32 [B][M] (the
+ * object's class frequency), num_objs i32 [B] (slots >= num_objs stay zero), flipped u8 [B],
+ * img_width i32 [B] (mirror axis), trans_output f64 [B][6] (get_affine_transform(c, s, 0,
+ * [out_w, out_h])).  Outputs (DEVICE, fully written): hm f32 [B][C][h][w], border_hm f32
+ * [B][1][h][w] or NULL, reg_mask u8 [B][M], ind i64 [B][M], poly f32 [B][M][2N], pseudo_depth
+ * f32 [B][M][1], peak / reg / wh f32 [B][M][2], freq_mask f32 [B] (mean over the image's
+ * objects, 1 when none).  rep: CP_REP_* (polar targets are (r, theta) pairs). */
+typedef struct cp_target_shape {
+  int32_t B, max_objs, nbr_points, num_classes, out_h, out_w, rep, no_reorder_flip;
+} cp_target_shape;
+size_t cp_polydet_targets_workspace_bytes(const cp_target_shape* s);
+int cp_polydet_targets(const cp_target_shape* s, const double* bbox_xywh, const double* poly_xy,
+                       const int32_t* cls_id, const float* pseudo_depth_in, const float* class_freq,
+                       const int32_t* num_objs, const uint8_t* flipped, const int32_t* img_width,
+                       const double* trans_output, float* hm, float* border_hm, uint8_t* reg_mask,
+                       int64_t* ind, float* poly, float* pseudo_depth, float* peak, float* reg,
+                       float* wh, float* freq_mask, void* workspace, size_t workspace_bytes,
+                       void* stream);
+
 /* --------------------------- fused training BatchNorm2d (+residual) (+ReLU) --
  * y = act(bn(x) + residual) with batch statistics (torch.nn.BatchNorm2d training semantics:
  * biased variance for normalisation, running stats updated with `momentum`, unbiased variance).

@@ -1,0 +1,166 @@
+"""Training-target construction: oracle/targets.py against the reference's own helpers
+(tests/golden/targets_prims.npz, CPU) and the HIP kernels behind cp_polydet_targets against
+the oracle (GPU: indices / masks bit-exact, float targets to 1 ulp of fp32)."""
+import numpy as np
+import pytest
+import torch
+
+from centerpoly_amd import synth
+from oracle import post as opost
+from oracle import targets as otg
+
+
+def test_helpers_match_reference_golden(golden):
+    g = golden("targets_prims")
+    for (hh, ww), r in zip(g["radius_sizes"], g["radius"]):
+        assert otg.gaussian_radius((int(hh), int(ww))) == r
+    hm = np.zeros((48, 64), dtype=np.float32)
+    centers = synth.integers("targets/centers", (12, 2), 0, 48)
+    radii = synth.integers("targets/radii", (12,), 0, 9)
+    centers[0] = (0, 0)
+    centers[1] = (63, 47)
+    for (cx, cy), r in zip(centers, radii):
+        otg.draw_umich_gaussian(hm, (int(min(cx + 8, 63)), int(cy)), int(r))
+    assert np.array_equal(hm, g["splat_hm"])
+    pts = synth.uniform("targets/pts", (32, 2), -50.0, 2100.0)
+    got = np.stack([otg.affine_transform(p, g["affine_t"]) for p in pts])
+    assert np.array_equal(got, g["affine"])
+
+
+def _case(tag, in_h, in_w, N, rep, flipped, scale=1.0, n_objs=None):
+    anns = synth.raw_annotations("tg/" + tag, in_h, in_w, nbr_points=N, n_objs=n_objs)
+    c = np.array([in_w * 0.47, in_h * 0.55], np.float32)
+    s = max(in_h, in_w) * scale
+    oh, ow = in_h // 4, in_w // 4
+    t = opost.get_affine_transform(c, s, 0, [ow, oh])
+    return anns, t, flipped, in_w, oh, ow, N, rep
+
+
+def test_oracle_targets_invariants():
+    anns, t, flipped, width, oh, ow, N, rep = _case("inv", 512, 1024, 16, "cartesian", False)
+    r = otg.build_targets(anns, t, flipped, width, oh, ow, 8, 128, N, rep)
+    n = int(r["reg_mask"].sum())
+    assert 0 < n <= len(anns)
+    k = np.nonzero(r["reg_mask"])[0]
+    cy, cx = r["ind"][k] // ow, r["ind"][k] % ow
+    for kk, y, x in zip(k, cy, cx):
+        assert r["hm"][anns[kk]["cls_id"], y, x] == 1.0        # exact 1 at every centre
+        np.testing.assert_allclose(r["peak"][kk], np.array([x, y]) + r["reg"][kk], rtol=0, atol=1e-5)
+    assert (r["reg"] >= 0).all() and (r["reg"] < 1).all()
+    assert r["hm"].max() == 1.0 and r["border_hm"].max() == 1.0
+    # mirrored twice with the vertex re-ordering the polygon keeps its cyclic order
+    rf = otg.build_targets(anns, t, True, width, oh, ow, 8, 128, N, rep)
+    assert int(rf["reg_mask"].sum()) > 0 and not np.array_equal(rf["poly"], r["poly"])
+    # an image without objects: neutral frequency weight
+    assert otg.build_targets([], t, False, width, oh, ow, 8, 128, N, rep)["freq_mask"] == 1.0
+
+
+GPU_CASES = [
+    ("a", 512, 1024, 16, "cartesian", False, 1.0, None),
+    ("b", 512, 1024, 16, "cartesian", True, 0.7, None),
+    ("c", 384, 1280, 32, "cartesian", True, 1.3, 40),
+    ("d", 512, 1024, 24, "polar", False, 0.9, None),
+    ("e", 512, 1024, 24, "polar", True, 1.0, 25),
+    ("f", 256, 256, 16, "polar_fixed", True, 0.6, 12),
+]
+
+
+@pytest.mark.gpu
+def test_targets_kernel_vs_oracle_batch():
+    from centerpoly_amd.datasets.sample.polydet import build_targets, collate, pack_annotations
+    for rep in ("cartesian", "polar"):
+        cases = [c for c in GPU_CASES if c[4] == rep and c[1:3] == (512, 1024)]
+        N = cases[0][3]
+        packed, refs = [], []
+        for tag, in_h, in_w, n, rp, flipped, scale, n_objs in cases:
+            if n != N:
+                continue
+            anns, t, fl, width, oh, ow, _, _ = _case(tag, in_h, in_w, n, rp, flipped, scale, n_objs)
+            packed.append(pack_annotations(anns, t, fl, width, 128, N))
+            refs.append(otg.build_targets(anns, t, fl, width, oh, ow, 8, 128, N, rp))
+        raw = {k: v.cuda() for k, v in collate(packed).items()}
+        out = {k: v.cpu().numpy() for k, v in build_targets(raw, 128, 256, 8, rep=rep).items()}
+        for b, ref in enumerate(refs):
+            _compare(out, b, ref)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", GPU_CASES, ids=[c[0] for c in GPU_CASES])
+def test_targets_kernel_vs_oracle_single(case):
+    from centerpoly_amd.datasets.sample.polydet import build_targets, collate, pack_annotations
+    tag, in_h, in_w, N, rep, flipped, scale, n_objs = case
+    anns, t, fl, width, oh, ow, _, _ = _case(tag, in_h, in_w, N, rep, flipped, scale, n_objs)
+    ref = otg.build_targets(anns, t, fl, width, oh, ow, 8, 128, N, rep)
+    raw = {k: v.cuda() for k, v in collate([pack_annotations(anns, t, fl, width, 128, N)]).items()}
+    out = {k: v.cpu().numpy() for k, v in build_targets(raw, oh, ow, 8, rep=rep).items()}
+    _compare(out, 0, ref)
+
+
+def _ulp_close(a, b, ulps=1):
+    a, b = np.asarray(a, np.float32), np.asarray(b, np.float32)
+    tol = ulps * np.spacing(np.maximum(np.abs(a), np.abs(b)).astype(np.float32))
+    return np.all(np.abs(a.astype(np.float64) - b.astype(np.float64)) <= tol)
+
+
+def _compare(out, b, ref):
+    assert np.array_equal(out["reg_mask"][b], ref["reg_mask"])
+    assert np.array_equal(out["ind"][b], ref["ind"])
+    assert np.array_equal(out["pseudo_depth"][b], ref["pseudo_depth"])
+    for k in ("peak", "reg", "wh", "poly"):
+        assert _ulp_close(out[k][b], ref[k]), k
+    # heat maps: same support, values to 1 ulp (device exp vs numpy exp before the fp32 cast)
+    for k in ("hm", "border_hm"):
+        assert np.array_equal(out[k][b] > 0, ref[k] > 0), k
+        assert _ulp_close(out[k][b], ref[k]), k
+        assert np.array_equal(out[k][b] == 1.0, ref[k] == 1.0), k
+    np.testing.assert_allclose(out["freq_mask"][b], ref["freq_mask"], rtol=1e-6)
+
+
+@pytest.mark.gpu
+def test_targets_feed_the_loss():
+    """Targets built on the device drive PolydetLoss end to end (finite loss, non-zero grads)."""
+    from centerpoly_amd.datasets.sample.polydet import build_targets, collate, pack_annotations
+    from centerpoly_amd.opts import opts
+    from centerpoly_amd.trains.polydet import PolydetLoss
+    opt = opts().init(["polydet", "--arch", "smallhourglass", "--poly_loss", "l1+iou", "--nbr_points", "16"])
+    opt.device = torch.device("cuda")
+    anns, t, fl, width, oh, ow, N, rep = _case("loss", 256, 256, 16, "cartesian", False, 1.0, 10)
+    raw = {k: v.cuda() for k, v in collate([pack_annotations(anns, t, fl, width, 128, N)]).items()}
+    batch = build_targets(raw, oh, ow, 8, rep=rep)
+    g = torch.Generator().manual_seed(1)
+    leaves = {"hm": torch.randn(1, 8, oh, ow, generator=g).cuda().requires_grad_(),
+              "poly": torch.randn(1, 32, oh, ow, generator=g).cuda().requires_grad_(),
+              "pseudo_depth": torch.randn(1, 1, oh, ow, generator=g).cuda().requires_grad_(),
+              "reg": torch.randn(1, 2, oh, ow, generator=g).cuda().requires_grad_()}
+    outputs = [{k: v * 1.0 for k, v in leaves.items()}]      # the loss applies its sigmoid in place
+    loss, stats = PolydetLoss(opt)(outputs, batch)
+    assert torch.isfinite(loss)
+    loss.backward()
+    assert float(leaves["hm"].grad.abs().sum()) > 0 and float(leaves["poly"].grad.abs().sum()) > 0
+
+
+@pytest.mark.gpu
+def test_trainer_epoch_with_device_targets():
+    """--device_targets: loader packs raw annotations, PolydetTrainer.prepare_batch builds the
+    targets on the GPU, two optimisation steps run."""
+    import contextlib
+    import io
+    from centerpoly_amd.datasets.dataset_factory import get_dataset
+    from centerpoly_amd.models.model import create_model
+    from centerpoly_amd.opts import opts
+    from centerpoly_amd.trains.train_factory import train_factory
+    with contextlib.redirect_stdout(io.StringIO()):
+        opt = opts().init(["polydet", "--arch", "smallhourglass", "--device_targets", "--input_h", "256",
+                           "--input_w", "256", "--batch_size", "2", "--num_iters", "2",
+                           "--poly_loss", "l1+iou"])
+        Dataset = get_dataset(opt.dataset, opt.task)
+        opt = opts().update_dataset_info_and_set_heads(opt, Dataset)
+        ds = Dataset(opt, "train")
+    opt.device = torch.device("cuda")
+    torch.manual_seed(317)
+    model = create_model(opt.arch, opt.heads, opt.head_conv)
+    trainer = train_factory["polydet"](opt, model, torch.optim.Adam(model.parameters(), opt.lr))
+    trainer.set_device(opt.gpus, opt.chunk_sizes, opt.device)
+    loader = torch.utils.data.DataLoader(ds, batch_size=2, shuffle=False, num_workers=0)
+    stats, _ = trainer.train(1, loader)
+    assert np.isfinite(stats["loss"]) and stats["hm_l"] > 0 and stats["poly_l"] > 0
