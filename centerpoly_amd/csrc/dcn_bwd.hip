@@ -53,6 +53,7 @@ struct DcnBwdArgs {
   long long offset_bstride, mask_bstride, goff_bstride, gmask_bstride;
   int B, Cin, H, W, Cout, Ho, Wo;
   int stride, pad, dil, mask_is_logit;
+  int tpr;      // tiled kernels: 64-pixel tiles per image row (the last one may be partial)
 #ifdef CP_ABLATE
   int ablate;   // timing-only build: bit0 no consumption, bit1 no flush, bit2 no MFMA, bit3 no loads
 #endif
@@ -295,14 +296,17 @@ __global__ __launch_bounds__(256, WPS) void dcn_bwd_data_tiled_kernel(DcnBwdArgs
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int b = blockIdx.y;
   const int HWo = a.Ho * a.Wo, HW = a.H * a.W;
-  const int p0 = blockIdx.x * BM;
-  const int p = p0 + lane;                // always < HWo here (W % 64 == 0)
+  // the tile is a segment of up to 64 pixels of ONE row (the last tile of a row is partial
+  // when W is not a multiple of 64: its surplus lanes carry an empty recipe)
+  const int ty = blockIdx.x / a.tpr, tx0 = (blockIdx.x - ty * a.tpr) * BM;
+  const int p0 = ty * a.W + tx0;
+  const bool p_ok = tx0 + lane < a.W;
+  const int p = p_ok ? p0 + lane : p0;
   const int Ktot = a.Cin * TAPS;
-  const int ty = p0 / a.W, tx0 = p0 - ty * a.W;     // the tile is one row segment
   const int ry0 = ty - RR, rx0 = tx0 - RR;
 
   Recipe r;
-  build_recipe(a, b, p, true, r);
+  build_recipe(a, b, p, p_ok, r);
   // region offset of each tap's top-left corner, -1 when a corner leaves the region
   int rbase[TAPS];
   {
@@ -313,7 +317,7 @@ __global__ __launch_bounds__(256, WPS) void dcn_bwd_data_tiled_kernel(DcnBwdArgs
       const float py = (float)(ty * a.stride - a.pad + ky * a.dil) + off[(long long)(2 * t) * HWo + p];
       const float px = (float)((tx0 + lane) * a.stride - a.pad + kx * a.dil) +
                        off[(long long)(2 * t + 1) * HWo + p];
-      const bool inside = py > -1.f && px > -1.f && py < (float)a.H && px < (float)a.W;
+      const bool inside = p_ok && py > -1.f && px > -1.f && py < (float)a.H && px < (float)a.W;
       const int y0 = (int)floorf(py), x0 = (int)floorf(px);
       const int ry = y0 - ry0, rx = x0 - rx0;
       rbase[t] = (inside && ry >= 0 && ry + 1 < RH && rx >= 0 && rx + 1 < RW) ? ry * RWP + rx
@@ -331,7 +335,7 @@ __global__ __launch_bounds__(256, WPS) void dcn_bwd_data_tiled_kernel(DcnBwdArgs
   // grad_out tile, staged once: goT[px][co]
   for (int idx = tid; idx < CP * BM; idx += 256) {
     const int co = idx / BM, pp = idx - co * BM;
-    goT[pp * LDO + co] = co < a.Cout ? gob[(long long)co * HWo + p0 + pp] : 0.f;
+    goT[pp * LDO + co] = (co < a.Cout && tx0 + pp < a.W) ? gob[(long long)co * HWo + p0 + pp] : 0.f;
   }
   for (int e = tid; e < KC * RSZ; e += 256) greg[e] = 0ull;
   for (int e = tid; e < CP * (LDW - KK); e += 256) {       // zero the pad columns once
@@ -508,6 +512,7 @@ __global__ __launch_bounds__(256, WPS) void dcn_bwd_data_tiled_kernel(DcnBwdArgs
   for (int q = wid; q < 27; q += 4) {
     const float v = red[(0 * 27 + q) * 64 + lane] + red[(1 * 27 + q) * 64 + lane] +
                     red[(2 * 27 + q) * 64 + lane] + red[(3 * 27 + q) * 64 + lane];
+    if (!p_ok) continue;
     if (q < 18) {
       if (a.goff) {
         const int t = q < 9 ? q : q - 9;
@@ -656,7 +661,7 @@ __global__ __launch_bounds__(256, WPS) void dcn_bwd_weight_tiled_kernel(DcnBwdAr
   const int co0 = blockIdx.z * SLAB;
   const int HWo = a.Ho * a.Wo, HW = a.H * a.W;
   const int Ktot = a.Cin * TAPS;
-  const int tiles = HWo / BM;
+  const int tiles = a.H * a.tpr;
   const float* gob = a.go + (long long)b * a.Cout * HWo;
   const float* xb = a.x + (long long)b * a.Cin * HW;
   // raw buffer loads (see the data kernel): per-lane 32-bit offsets, range-checked by hardware
@@ -682,11 +687,13 @@ __global__ __launch_bounds__(256, WPS) void dcn_bwd_weight_tiled_kernel(DcnBwdAr
 
   const int t_begin = grp * ex.T, t_end = min(tiles, t_begin + ex.T);
   for (int tile = t_begin; tile < t_end; ++tile) {
-    const int p0 = tile * BM, p = p0 + lane;
-    const int ty = p0 / a.W, tx0 = p0 - ty * a.W;
+    const int ty = tile / a.tpr, tx0 = (tile - ty * a.tpr) * BM;
+    const int p0 = ty * a.W + tx0;
+    const bool p_ok = tx0 + lane < a.W;     // partial last tile of a row when W % 64 != 0
+    const int p = p_ok ? p0 + lane : p0;
     const int ry0 = ty - RR, rx0 = tx0 - RR;
     Recipe r;
-    build_recipe(a, b, p, true, r);
+    build_recipe(a, b, p, p_ok, r);
     int rbase[TAPS];
     {
       const float* off = a.offset + (long long)b * a.offset_bstride;
@@ -696,7 +703,7 @@ __global__ __launch_bounds__(256, WPS) void dcn_bwd_weight_tiled_kernel(DcnBwdAr
         const float py = (float)(ty * a.stride - a.pad + ky * a.dil) + off[(long long)(2 * t) * HWo + p];
         const float px = (float)((tx0 + lane) * a.stride - a.pad + kx * a.dil) +
                          off[(long long)(2 * t + 1) * HWo + p];
-        const bool inside = py > -1.f && px > -1.f && py < (float)a.H && px < (float)a.W;
+        const bool inside = p_ok && py > -1.f && px > -1.f && py < (float)a.H && px < (float)a.W;
         const int y0 = (int)floorf(py), x0 = (int)floorf(px);
         const int ry = y0 - ry0, rx = x0 - rx0;
         rbase[t] = (inside && ry >= 0 && ry + 1 < RH && rx >= 0 && rx + 1 < RW) ? ry * RWP + rx
@@ -722,11 +729,14 @@ __global__ __launch_bounds__(256, WPS) void dcn_bwd_weight_tiled_kernel(DcnBwdAr
     issue(cs0);
     __syncthreads();                       // previous tile's MFMA reads of goT/colT are done
     {                                      // grad_out tile: thread -> pixel lane, rows wid, wid+4, ...
-      const unsigned gbase = ((unsigned)(co0 + swid) * (unsigned)HWo + (unsigned)(p0 + lane)) * 4u;
+      // lanes of a partial tile keep one out-of-range offset for every row (reads 0)
+      const unsigned gbase = p_ok ? ((unsigned)(co0 + swid) * (unsigned)HWo + (unsigned)(p0 + lane)) * 4u
+                                  : 0xf0000000u;
+      const unsigned gstep = p_ok ? (unsigned)HWo * 16u : 0u;       // 4 rows of grad_out
 #pragma unroll
       for (int i = 0; i < SLAB / 4; ++i)   // rows past Cout are past num_records and read 0
         goT[lane * LDS_ + swid + 4 * i] = __builtin_bit_cast(
-            float, __builtin_amdgcn_raw_buffer_load_b32(rs_go, gbase + (unsigned)(4 * i) * (unsigned)HWo * 4u, 0, 0));
+            float, __builtin_amdgcn_raw_buffer_load_b32(rs_go, gbase + (unsigned)i * gstep, 0, 0));
     }
 #pragma unroll
     for (int h = 0; h < WCH; ++h) {
@@ -863,32 +873,35 @@ extern "C" int cp_dcn_v2_backward(const cp_dcn_shape* s, const float* x, const f
 #endif
   hipStream_t st = (hipStream_t)stream;
   const int tiles = (Ho * Wo + BM - 1) / BM;
+  a.tpr = (s->W + BM - 1) / BM;
+  const int row_tiles = s->H * a.tpr;       // tiled kernels: tiles never straddle rows
+  const bool same_size = s->stride == 1 && Wo == s->W && Ho == s->H &&
+                         (unsigned long long)s->Cout * Ho * Wo * 4ull < 0xE0000000ull;
   if (grad_x || grad_offset || grad_mask) {
-    const bool tiled = s->Cout <= 256 && s->stride == 1 && Wo == s->W && Ho == s->H &&
-                       (s->W % BM) == 0;
+    const bool tiled = s->Cout <= 256 && same_size;
     if (tiled) {
-      if (s->Cout <= 64) launch_tiled<64, 2>(a, tiles, st);
-      else if (s->Cout <= 128) launch_tiled<128, 1>(a, tiles, st);
-      else launch_tiled<256, 1>(a, tiles, st);
+      if (s->Cout <= 64) launch_tiled<64, 2>(a, row_tiles, st);
+      else if (s->Cout <= 128) launch_tiled<128, 1>(a, row_tiles, st);
+      else launch_tiled<256, 1>(a, row_tiles, st);
     } else {
       const size_t lds = (size_t)(BM * LDC + COC * LDK + BM * 49) * sizeof(float);
       hipLaunchKernelGGL(dcn_bwd_data_kernel, dim3(tiles, s->B), dim3(256), lds, st, a);
     }
   }
   if (grad_weight) {
-    const bool tiled_w = s->stride == 1 && Wo == s->W && Ho == s->H && (s->W % BM) == 0;
+    const bool tiled_w = same_size;
     const int slab = s->Cout <= 64 ? 64 : COC;
     const int slabs = (s->Cout + slab - 1) / slab;
     if (tiled_w) {
       const int slices = (s->Cin + WSC - 1) / WSC;
-      const long long blocks1 = (long long)tiles * s->B * slices * slabs;
+      const long long blocks1 = (long long)row_tiles * s->B * slices * slabs;
       int T = (int)(blocks1 / 2048);
       if (T < 1) T = 1;
       if (T > 16) T = 16;
-      if (T > tiles) T = tiles;
+      if (T > row_tiles) T = row_tiles;
       WTiledExtra ex;
       ex.T = T;
-      ex.groups_per_image = (tiles + T - 1) / T;
+      ex.groups_per_image = (row_tiles + T - 1) / T;
       const size_t lds = (size_t)(BM * (slab + 1) + BM * 49 + KC * RSZ) * sizeof(float);
       const dim3 grid(ex.groups_per_image * s->B, slices, slabs);
       if (slab == 64)

@@ -397,8 +397,12 @@ def test_dcn_fused_bn_relu_epilogue():
 
 
 DCN_BWD_SHAPES = [(1, 16, 24, 12, 20), (2, 8, 140, 9, 11), (1, 64, 64, 16, 32), (1, 130, 32, 8, 8),
-                  # W % 64 == 0 -> LDS-region (tiled) data kernel, all three Cout tiles
-                  (1, 16, 24, 6, 64), (2, 10, 70, 5, 128), (1, 6, 200, 4, 64), (1, 64, 64, 9, 192)]
+                  # whole 64-pixel row tiles, all three Cout tiles of the LDS-region kernels
+                  (1, 16, 24, 6, 64), (2, 10, 70, 5, 128), (1, 6, 200, 4, 64), (1, 64, 64, 9, 192),
+                  # partial last tile per row (KITTI-shaped widths 160 / 80, and 64 + 1)
+                  (1, 16, 16, 6, 160), (2, 8, 24, 5, 80), (1, 12, 8, 3, 65),
+                  # Cout > 256 -> generic kernels
+                  (1, 8, 260, 4, 16)]
 
 
 @pytest.mark.parametrize("shape", DCN_BWD_SHAPES, ids=lambda s: "x".join(map(str, s)))
