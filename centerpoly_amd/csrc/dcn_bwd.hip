@@ -383,8 +383,12 @@ __global__ __launch_bounds__(256, WPS) void dcn_bwd_data_tiled_kernel(DcnBwdArgs
       xr[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_x, roff[i], xsoff, 0));
   };
   issue(0);
+  __syncthreads();                         // goT / greg / pad columns initialised
   for (int c0 = 0; c0 < a.Cin; c0 += KC) {
-    __syncthreads();                       // previous chunk fully consumed / flushed
+    // Two barriers per chunk.  wT is only read in the MFMA phase (closed by the barrier after
+    // it), xreg / greg belong to ONE wave (LDS operations of a wave complete in order), and
+    // gcT / smax are rewritten only after the staging barrier, which every wave reaches after
+    // it has consumed the previous chunk.
 #pragma unroll
     for (int i = 0; i < WPT; ++i) {
       const int idx = tid + i * 256;
@@ -481,9 +485,9 @@ __global__ __launch_bounds__(256, WPS) void dcn_bwd_data_tiled_kernel(DcnBwdArgs
         }
       }
     }
-    __syncthreads();
-    // ---- flush: each wave empties its own channel's region, one coalesced global atomic per
-    // touched in-image cell (the cell's byte offset is the staging offset) ----
+    // ---- flush: each wave empties its own channel's region (no barrier: wave-private), one
+    // coalesced global atomic per touched in-image cell (the cell's byte offset is the staging
+    // offset) ----
     if (gxb && !CP_ABL(2) && c < a.Cin) {
       unsigned long long* gw_ = greg + swid * RSZ;
       float* gplane = gxb + (long long)c * HW;
@@ -741,10 +745,9 @@ __global__ __launch_bounds__(256, WPS) void dcn_bwd_weight_tiled_kernel(DcnBwdAr
 #pragma unroll
     for (int h = 0; h < WCH; ++h) {
       const int c0 = cs0 + h * KC;
-      __syncthreads();                     // colT / xreg free again
-#pragma unroll
+      __syncthreads();                     // colT free again (xreg is wave-private: no barrier
+#pragma unroll                             // between its store and the reads below)
       for (int i = 0; i < RPW; ++i) xreg[swid * RSZ + lane + 64 * i] = xr[i];
-      __syncthreads();
       if (h + 1 < WCH) issue(c0 + KC);     // next chunk's region loads fly during sampling + MFMA
       // ---- sample: wave w handles channel c0 + w ----
       {

@@ -71,15 +71,13 @@ class BaseDetector(object):
         return images, meta
 
     def _upload(self, image):
-        """8-bit HWC image -> device through a cached pinned staging buffer."""
+        """8-bit HWC image -> device.  A plain (pageable) copy: measured on MI355X it costs
+        0.17 ms for a 2048x1024 image and is steady, while staging through a pinned buffer with
+        a non-blocking copy showed periodic ~90 ms stalls (tools/probe_stalls.py)."""
         if image.dtype != np.uint8 or image.ndim != 3 or image.shape[2] != 3:
             raise TypeError("pre_process needs an 8-bit [H,W,3] image (got %s %s)"
                             % (image.dtype, image.shape))
-        pin = getattr(self, "_pin", None)
-        if pin is None or tuple(pin.shape) != tuple(image.shape):
-            pin = self._pin = torch.empty(image.shape, dtype=torch.uint8).pin_memory()
-        pin.copy_(torch.from_numpy(np.ascontiguousarray(image)))
-        return pin.to(self.opt.device, non_blocking=True)
+        return torch.from_numpy(np.ascontiguousarray(image)).to(self.opt.device)
 
     def process(self, images, return_time=False):
         raise NotImplementedError

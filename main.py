@@ -47,7 +47,7 @@ def main(opt):
 
     per_rank = max(1, opt.batch_size // world)
     val_loader = torch.utils.data.DataLoader(Dataset(opt, "val"), batch_size=1, shuffle=False,
-                                             num_workers=1, pin_memory=True)
+                                             num_workers=1, pin_memory=False)
     if opt.test:
         _, preds = trainer.val(0, val_loader)
         val_loader.dataset.run_eval(preds, opt.save_dir)
@@ -56,7 +56,11 @@ def main(opt):
     sampler = torch.utils.data.distributed.DistributedSampler(train_set) if world > 1 else None
     train_loader = torch.utils.data.DataLoader(train_set, batch_size=per_rank, shuffle=sampler is None,
                                                sampler=sampler, num_workers=opt.num_workers,
-                                               pin_memory=True, drop_last=True)
+                                               # pageable batches: 100 MB reach the GPU in 1.9 ms, while host
+                                               # writes into pinned staging memory followed by non-blocking
+                                               # copies showed periodic ~90 ms stalls on MI355X
+                                               # (tools/probe_stalls.py); the reference pins (main.py:59)
+                                               pin_memory=False, drop_last=True)
     if rank == 0:
         os.makedirs(opt.save_dir, exist_ok=True)
     print("Starting training...")

@@ -22,7 +22,7 @@ def main():
         det = detector_factory["polydet"](opt)
     img = (synth.uniform("probe/img", (h, w, 3)) * 255).astype(np.uint8)
     keys = ["tot", "load", "pre", "net", "dec", "post", "merge"]
-    for it in range(8):
+    for it in range(40):
         ret = det.run(img)
         print(it, " ".join("%s %.2fms" % (k, 1e3 * ret[k]) for k in keys), flush=True)
 
