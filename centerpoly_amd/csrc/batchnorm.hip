@@ -172,8 +172,8 @@ __global__ void bn_bwd_finalize_kernel(const double* __restrict__ partial, BnDim
   double s = 0, q = 0;
   for (int i = 0; i < n; ++i) { s += partial[2 * ((long long)c * n + i)]; q += partial[2 * ((long long)c * n + i) + 1]; }
   const double N = (double)d.B * (double)d.HW;
-  if (grad_b) grad_b[c] += (float)s;
-  if (grad_w) grad_w[c] += (float)q;
+  if (grad_b) grad_b[c] = (float)s;
+  if (grad_w) grad_w[c] = (float)q;
   coef[2 * c] = (float)(s / N);
   coef[2 * c + 1] = (float)(q / N);
 }

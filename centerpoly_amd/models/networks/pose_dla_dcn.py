@@ -97,8 +97,8 @@ class _BnAct(torch.autograd.Function):
         B, C, H, W = x.shape
         gx = torch.empty_like(x)
         gres = torch.empty_like(x) if has_res else None
-        gw = torch.zeros(C, dtype=torch.float32, device=x.device)
-        gb = torch.zeros(C, dtype=torch.float32, device=x.device)
+        gw = torch.empty(C, dtype=torch.float32, device=x.device)       # overwritten by the kernel
+        gb = torch.empty(C, dtype=torch.float32, device=x.device)
         ws = _C.workspace(L.cp_bn_workspace_bytes(B, C, H * W), x.device)
         rc = L.cp_bn_act_backward(_C.ptr(x), _C.ptr(y), _C.ptr(gy), _C.ptr(weight), _C.ptr(mean),
                                   _C.ptr(invstd), 1 if relu else 0, _C.ptr(gx), _C.ptr(gres), _C.ptr(gw),

@@ -203,7 +203,7 @@ int cp_polydet_targets(const cp_target_shape* s, const double* bbox_xywh, const 
  * Replaces the BN -> add -> ReLU chains of DeformConv / BasicBlock / Root / conv levels
  * (src/lib/models/networks/pose_dla_dcn.py:32-60,148-166,266-277,347-359) in training.
  * x, y, residual and their gradients: fp32 [B,C,H,W], HW = H x W; weight, bias, running and
- * saved statistics: [C].  backward: grad_weight / grad_bias are ACCUMULATED INTO; grad_residual (may be NULL) receives
+ * saved statistics: [C].  backward: grad_weight / grad_bias are OVERWRITTEN; grad_residual (may be NULL) receives
  * the post-activation gradient; workspace from cp_bn_workspace_bytes. */
 size_t cp_bn_workspace_bytes(int32_t B, int32_t C, int64_t HW);
 int cp_bn_act_forward_train(const float* x, const float* weight, const float* bias,
