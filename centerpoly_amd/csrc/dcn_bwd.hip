@@ -29,6 +29,7 @@
 // the region fall back to global gathers / atomics.  The generic kernel below it covers
 // every other shape.
 #include "cp_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -714,6 +715,9 @@ __global__ __launch_bounds__(256, WPS) void dcn_bwd_weight_tiled_kernel(DcnBwdAr
                    : (inside ? -1 : -2);
       }
     }
+    bool any_fallback = false;
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t) any_fallback |= rbase[t] == -1;
     unsigned roff[RPW];                    // this wave's region cells (channel c0 + w), per tile
 #pragma unroll
     for (int i = 0; i < RPW; ++i) {
@@ -750,6 +754,51 @@ __global__ __launch_bounds__(256, WPS) void dcn_bwd_weight_tiled_kernel(DcnBwdAr
       for (int i = 0; i < RPW; ++i) xreg[swid * RSZ + lane + 64 * i] = xr[i];
       if (h + 1 < WCH) issue(c0 + KC);     // next chunk's region loads fly during sampling + MFMA
       // ---- sample: wave w handles channel c0 + w ----
+      // (the 64-channel slab has the registers for the batched, branch-free form: -11 % on
+      // 64->64 @256x512; on the 128 slab the same form cost +13..26 %, it keeps the per-tap form)
+      if constexpr (SLAB == 64)
+      {
+        const int c = c0 + wid;
+        const bool c_ok = c < a.Cin;
+        const float* xw = xreg + wid * RSZ;
+        // hot pass, branch-free: all 36 region reads are issued back to back (clamped address,
+        // the result is dropped by a select when the tap is not served by the region)
+        float v[TAPS][4];
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t) {
+          const int rbc = max(rbase[t], 0);
+          v[t][0] = xw[rbc];
+          v[t][1] = xw[rbc + 1];
+          v[t][2] = xw[rbc + RWP];
+          v[t][3] = xw[rbc + RWP + 1];
+        }
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t) {
+          const float ly = r.ly[t], lx = r.lx[t], hy = 1.f - ly, hx = 1.f - lx;
+          const float val = (hy * hx * v[t][0] + hy * lx * v[t][1] + ly * hx * v[t][2] + ly * lx * v[t][3]) * r.m[t];
+          colT[lane * LDW2 + wid * TAPS + t] = (rbase[t] >= 0 && c_ok) ? val : 0.f;
+        }
+        // cold pass (wave-uniform skip): taps whose corners leave the region gather from memory
+        if (c_ok && __builtin_amdgcn_ballot_w64(any_fallback) != 0ull) {
+          const float* xc = xb + (long long)c * HW;
+#pragma unroll
+          for (int t = 0; t < TAPS; ++t) {
+            if (rbase[t] != -1) continue;
+            const unsigned vb = corner_bits(r, t);
+            const int dx = (r.step >> (2 * t)) & 1;
+            const int dy = ((r.step >> (2 * t + 1)) & 1) ? a.W : 0;
+            const float* q = xc + r.base[t];
+            const float v00 = (vb & 1u) ? q[0] : 0.f;
+            const float v01 = (vb & 2u) ? q[dx] : 0.f;
+            const float v10 = (vb & 4u) ? q[dy] : 0.f;
+            const float v11 = (vb & 8u) ? q[dy + dx] : 0.f;
+            const float ly = r.ly[t], lx = r.lx[t], hy = 1.f - ly, hx = 1.f - lx;
+            colT[lane * LDW2 + wid * TAPS + t] =
+                (hy * hx * v00 + hy * lx * v01 + ly * hx * v10 + ly * lx * v11) * r.m[t];
+          }
+        }
+      }
+      else
       {
         const int c = c0 + wid;
         const bool c_ok = c < a.Cin;
