@@ -382,6 +382,50 @@ def test_dcn_zero_offset_known_answer():
     np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), rtol=1e-4, atol=1e-5)
 
 
+def test_dcn_full_size_properties():
+    """BASELINE config 2's dominant layer (64->64 @256x512, the launch bench.py reports), too big
+    for the oracle in a test: size-independent properties instead -- zero offsets reproduce the
+    library convolution, the op is linear in x and in the weight, integer offsets are a shifted
+    convolution tap, and an 8-bit-exact split of the batch gives the batched result."""
+    from centerpoly_amd.models.networks.DCNv2.dcn_v2 import dcn_v2_forward_raw
+    Cin, Cout, H, W = 64, 64, 256, 512
+    x = g(synth.normal("dcn/full/x", (2, Cin, H, W)))
+    w = g(synth.normal("dcn/full/w", (Cout, Cin, 3, 3), 0.0, 0.05))
+    b = g(synth.normal("dcn/full/b", (Cout,)))
+    zero = torch.zeros(2, 27, H, W, device=DEV)
+    out0 = dcn_v2_forward_raw(x, zero, w, b)
+    ref0 = 0.5 * torch.nn.functional.conv2d(x, w, None, padding=1) + b.view(1, -1, 1, 1)
+    torch.testing.assert_close(out0, ref0, rtol=1e-4, atol=1e-4)
+    om = g(synth.normal("dcn/full/om", (2, 27, H, W), 0.0, 1.5))
+    base = dcn_v2_forward_raw(x, om, w, b)
+    nb = torch.zeros_like(b)
+    lin = dcn_v2_forward_raw(2.0 * x, om, w, nb) - 2.0 * dcn_v2_forward_raw(x, om, w, nb)
+    assert float(lin.abs().max()) <= 1e-4 * float(base.abs().max())
+    w2 = g(synth.normal("dcn/full/w2", (Cout, Cin, 3, 3), 0.0, 0.05))
+    add = dcn_v2_forward_raw(x, om, w + w2, nb) - dcn_v2_forward_raw(x, om, w, nb) - dcn_v2_forward_raw(x, om, w2, nb)
+    assert float(add.abs().max()) <= 2e-4 * float(base.abs().max())
+    # batch entries are independent
+    one = dcn_v2_forward_raw(x[1:2].contiguous(), om[1:2].contiguous(), w, b)
+    assert torch.equal(one[0], base[1])
+    # integer offset (+1 row, +2 columns on every tap) == the zero-offset result of the shifted image
+    sh = torch.zeros(1, 27, H, W, device=DEV)
+    sh[:, 0:18:2] = 1.0
+    sh[:, 1:18:2] = 2.0
+    xs = torch.zeros_like(x[:1])
+    xs[:, :, :H - 1, :W - 2] = x[:1, :, 1:, 2:]
+    a1 = dcn_v2_forward_raw(x[:1].contiguous(), sh, w, b)
+    a2 = dcn_v2_forward_raw(xs, zero[:1].contiguous(), w, b)
+    torch.testing.assert_close(a1[:, :, 2:H - 2, 2:W - 4], a2[:, :, 2:H - 2, 2:W - 4], rtol=1e-5, atol=1e-5)
+
+
+def test_dcn_rejects_unsupported_shapes():
+    from centerpoly_amd.models.networks.DCNv2.dcn_v2 import dcn_v2_forward_raw
+    x = torch.zeros(1, 4, 8, 1, device=DEV)                 # W = 1: the x-pair gathers need two columns
+    with pytest.raises(_C.NativeError):
+        dcn_v2_forward_raw(x, torch.zeros(1, 27, 8, 1, device=DEV), torch.zeros(4, 4, 3, 3, device=DEV),
+                           torch.zeros(4, device=DEV))
+
+
 def test_dcn_fused_bn_relu_epilogue():
     from centerpoly_amd.models.networks.pose_dla_dcn import DeformConv
     m = DeformConv(32, 64).to(DEV)

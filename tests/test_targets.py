@@ -164,3 +164,25 @@ def test_trainer_epoch_with_device_targets():
     loader = torch.utils.data.DataLoader(ds, batch_size=2, shuffle=False, num_workers=0)
     stats, _ = trainer.train(1, loader)
     assert np.isfinite(stats["loss"]) and stats["hm_l"] > 0 and stats["poly_l"] > 0
+
+
+@pytest.mark.gpu
+def test_targets_edge_cases():
+    """No objects, more annotations than slots, and objects that the crop pushes fully outside
+    (skipped slots stay zero but keep their index, as in the reference's loop)."""
+    from centerpoly_amd.datasets.sample.polydet import build_targets, collate, pack_annotations
+    N, M = 16, 8
+    t = opost.get_affine_transform(np.array([256., 128.], np.float32), 512.0, 0, [128, 64])
+    many = synth.raw_annotations("tg/many", 256, 512, nbr_points=N, n_objs=20)
+    far = [dict(a) for a in synth.raw_annotations("tg/far", 256, 512, nbr_points=N, n_objs=5)]
+    for a in far[1:4]:                                       # move three objects far outside the image
+        a["bbox"] = [a["bbox"][0] + 5000.0, a["bbox"][1], a["bbox"][2], a["bbox"][3]]
+        a["poly"] = [v + 5000.0 if i % 2 == 0 else v for i, v in enumerate(a["poly"])]
+    cases = [[], many, far]
+    raw = {k: v.cuda() for k, v in collate([pack_annotations(c, t, False, 512, M, N) for c in cases]).items()}
+    out = {k: v.cpu().numpy() for k, v in build_targets(raw, 64, 128, 8).items()}
+    for b, anns in enumerate(cases):
+        _compare(out, b, otg.build_targets(anns, t, False, 512, 64, 128, 8, M, N, "cartesian"))
+    assert out["reg_mask"][0].sum() == 0 and out["freq_mask"][0] == 1.0 and out["hm"][0].max() == 0.0
+    assert out["reg_mask"][1].sum() <= M
+    assert list(out["reg_mask"][2][1:4]) == [0, 0, 0]
