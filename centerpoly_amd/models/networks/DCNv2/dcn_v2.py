@@ -39,7 +39,7 @@ def dcn_v2_forward_raw(x, om, weight, bias, stride=1, pad=1, dil=1, dg=1, ep_sca
     nws = L.cp_dcn_v2_forward_workspace_bytes(s)
     ws = _C.workspace(nws, x.device) if nws else None
     timer = _C.kernel_timer
-    end = timer.start(("dcn_fwd", s.Cin, s.Cout, Ho, Wo)) if timer is not None else None
+    end = timer.start(("dcn_fwd", s.Cin, s.Cout, Ho, Wo, s.B)) if timer is not None else None
     rc = L.cp_dcn_v2_forward(s, _C.ptr(x), _C.ptr(om), bs, mask_ptr, bs, 1, _C.ptr(weight),
                              _C.ptr(bias), _C.ptr(ep_scale), _C.ptr(ep_shift), 1 if relu else 0,
                              _C.DCN_CONTRACTION[contraction], _C.ptr(out), _C.ptr(ws), nws, _C.stream())
