@@ -479,20 +479,33 @@ class DLASeg(nn.Module):
         fcs = [getattr(self, h) for h in self.heads]
         if all(isinstance(fc, nn.Sequential) and len(fc) == 3 for fc in fcs):
             with torch.no_grad():
-                self._heads_cat = (torch.cat([fc[0].weight for fc in fcs], 0).contiguous(),
-                                   torch.cat([fc[0].bias for fc in fcs], 0).contiguous())
+                tails = [(fc[2].weight.reshape(fc[2].out_channels, -1).t().contiguous(),
+                          fc[2].bias.detach().clone() if fc[2].bias is not None else None,
+                          fc[0].out_channels, fc[2].out_channels) for fc in fcs]
+                fast = all(fc[2].kernel_size == (1, 1) and fc[2].out_channels <= 32 and fc[0].bias is not None
+                           and fc[0].kernel_size == (3, 3) for fc in fcs)
+                if fast:
+                    self._heads_cat = (torch.cat([fc[0].weight for fc in fcs], 0).contiguous(),
+                                       torch.cat([fc[0].bias for fc in fcs], 0).contiguous(), tails)
         return self
 
     def _heads_fast(self, feat):
-        """All heads' conv3x3 as ONE convolution (they share the input), one fused bias+ReLU
-        pass, then the per-head 1x1 convolutions on channel slices."""
-        w, b = self._heads_cat
-        y = _conv_folded(feat, getattr(self, next(iter(self.heads)))[0], (w, b), relu=True)
+        """All heads' conv3x3 as ONE library convolution (they share the input); each head's
+        bias + ReLU + 1x1 convolution is then one streaming kernel over its channel slice of the
+        raw result (cp_conv1x1_act_forward) -- the 4x256-channel tensor is read once instead of
+        going through a bias/ReLU pass and a GEMM with a handful of output rows."""
+        w, b, tails = self._heads_cat
+        y = F.conv2d(feat, w, None, padding=1)
+        B, ctot, H, W = y.shape
+        hw = H * W
         out, c0 = {}, 0
-        for h in self.heads:
-            fc = getattr(self, h)
-            hc = fc[0].out_channels
-            out[h] = fc[2](y[:, c0:c0 + hc])
+        L = _C.lib()
+        for h, (w_t, b1, hc, co) in zip(self.heads, tails):
+            o = torch.empty((B, co, H, W), dtype=torch.float32, device=y.device)
+            _C.check(L.cp_conv1x1_act_forward(
+                _C.c_void_p(y.data_ptr() + 4 * c0 * hw), ctot * hw, _C.c_void_p(b.data_ptr() + 4 * c0), 1,
+                _C.ptr(w_t), _C.ptr(b1), _C.ptr(o), B, hc, co, hw, _C.stream()), "cp_conv1x1_act_forward")
+            out[h] = o
             c0 += hc
         return out
 
@@ -509,7 +522,8 @@ class DLASeg(nn.Module):
         y = [x[i].clone() for i in range(self.last_level - self.first_level)]
         self.ida_up(y, 0, len(y))
         if getattr(self, "_heads_cat", None) is not None and not self.training \
-                and not torch.is_grad_enabled() and y[-1].is_cuda:
+                and not torch.is_grad_enabled() and y[-1].is_cuda \
+                and (y[-1].shape[2] * y[-1].shape[3]) % 4 == 0:
             return [self._heads_fast(y[-1])]
         return [{head: getattr(self, head)(y[-1]) for head in self.heads}]
 

@@ -143,6 +143,18 @@ int cp_depthwise_up_backward(const float* x, const float* weight, const float* g
 int cp_bias_act_inplace(float* y, const float* bias, const float* residual, int32_t B, int32_t C,
                         int64_t HW, int32_t relu, void* stream);
 
+/* Output stage of a detection head at inference (the `fc` Sequential of DLASeg,
+ * src/lib/models/networks/pose_dla_dcn.py:445-462: Conv2d 3x3 + bias -> ReLU -> Conv2d 1x1 + bias),
+ * everything after the 3x3 convolution's matrix product, one pass:
+ *   out[b][o][p] = bias[o] + sum_c w_t[c][o] * act(y[b][c][p] + in_bias[c])
+ * y: raw 3x3-conv output, channel slice of a larger tensor allowed (y_bstride = elements between
+ * images); in_bias [Cin] or NULL; relu_in != 0 applies ReLU; w_t is the 1x1 weight TRANSPOSED to
+ * [Cin][Cout]; bias [Cout] or NULL; out [B][Cout][HW].  Cout <= 32, HW % 4 == 0, 16-byte aligned
+ * y / out (otherwise CP_EUNSUPPORTED). */
+int cp_conv1x1_act_forward(const float* y, int64_t y_bstride, const float* in_bias, int32_t relu_in,
+                           const float* w_t, const float* bias, float* out, int32_t B, int32_t Cin,
+                           int32_t Cout, int64_t HW, void* stream);
+
 /* ------------------------------------------------ detector pre/post-processing --
  * cp_preprocess_warp_normalize: the cv2 stage of BaseDetector.pre_process
  * (src/lib/detectors/base_detector.py:66-87): cv2.warpAffine(image, trans_input, (dst_w, dst_h),

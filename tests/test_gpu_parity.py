@@ -426,6 +426,30 @@ def test_dcn_rejects_unsupported_shapes():
                            torch.zeros(4, device=DEV))
 
 
+@pytest.mark.parametrize("cin,cout,hw,relu", [(256, 8, (32, 64), True), (256, 32, (32, 64), True), (256, 1, (16, 20), True),
+                                              (256, 2, (16, 20), True), (70, 20, (9, 12), False), (5, 3, (2, 2), True)])
+def test_head_output_stage_vs_torch(cin, cout, hw, relu):
+    """cp_conv1x1_act_forward on a channel slice of a larger tensor == conv1x1(relu(y + b3)) + b1."""
+    H, W = hw
+    ytot = g(synth.normal("head/y%d_%d" % (cin, cout), (2, cin + 7, H, W)))
+    b3 = g(synth.normal("head/b3", (cin + 7,)))
+    w1 = g(synth.normal("head/w1%d_%d" % (cin, cout), (cout, cin), 0.0, 0.1))
+    b1 = g(synth.normal("head/b1", (cout,)))
+    c0 = 4
+    out = torch.empty(2, cout, H, W, device=DEV)
+    _C.check(_C.lib().cp_conv1x1_act_forward(
+        _C.c_void_p(ytot.data_ptr() + 4 * c0 * H * W), (cin + 7) * H * W, _C.c_void_p(b3.data_ptr() + 4 * c0),
+        1 if relu else 0, _C.ptr(w1.t().contiguous()), _C.ptr(b1), _C.ptr(out), 2, cin, cout, H * W, _C.stream()), "head")
+    x = ytot[:, c0:c0 + cin] + b3[c0:c0 + cin].view(1, -1, 1, 1)
+    if relu:
+        x = x.relu()
+    ref = torch.nn.functional.conv2d(x.double(), w1.double().view(cout, cin, 1, 1), b1.double()).float()
+    torch.testing.assert_close(out, ref, rtol=1e-5, atol=1e-5)
+    # unsupported shapes are refused, not approximated
+    assert _C.lib().cp_conv1x1_act_forward(_C.ptr(ytot), 0, None, 0, _C.ptr(w1), None, _C.ptr(out), 1, cin, 33, 4,
+                                           _C.stream()) == -2
+
+
 def test_dcn_fused_bn_relu_epilogue():
     from centerpoly_amd.models.networks.pose_dla_dcn import DeformConv
     m = DeformConv(32, 64).to(DEV)
