@@ -305,8 +305,10 @@ DCN_SHAPES = [
     (1, 512, 256, 8, 16),
     (1, 256, 256, 12, 20),
     (2, 24, 40, 13, 19),        # ragged: channels not multiples of the tile, odd extent
-    (1, 8, 300, 9, 7),          # Cout > 256 -> two N tiles
-    # W % 64 == 0 -> direct-operand kernel (LDS input region), all three N tiles, ragged Cin
+    (1, 8, 300, 9, 7),          # Cout > 256 -> three 128-wide N tiles
+    (1, 12, 20, 7, 2),          # narrowest supported width: every x-pair gather starts at column 0
+    (2, 9, 33, 5, 3),
+    # wide rows, ragged Cin
     (1, 24, 40, 5, 128),
     (2, 130, 200, 4, 64),
     (1, 64, 128, 6, 192),
