@@ -124,6 +124,57 @@ extern "C" int cp_bias_act_inplace(float* y, const float* bias, const float* res
   return cp_launch_status();
 }
 
+// Backward of y = relu(conv + bias) (the in-place epilogue above, training): one pass
+//     g = grad_out * [y > 0],   grad_bias[c] += sum_{b,p} g
+// instead of the library's threshold_backward pass followed by a separate bias reduction.
+namespace {
+__global__ __launch_bounds__(256) void bias_relu_bwd_kernel(const float* __restrict__ y,
+                                                            const float* __restrict__ go,
+                                                            float* __restrict__ g,
+                                                            float* __restrict__ gbias, int C,
+                                                            long long HW) {
+  const int bc = blockIdx.y;
+  const long long base = (long long)bc * HW;
+  const long long n4 = HW >> 2;
+  float s = 0.f;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    const f32x4 yv = reinterpret_cast<const f32x4*>(y + base)[i];
+    f32x4 v = reinterpret_cast<const f32x4*>(go + base)[i];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      v[k] = yv[k] > 0.f ? v[k] : 0.f;
+      s += v[k];
+    }
+    reinterpret_cast<f32x4*>(g + base)[i] = v;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (HW & 3)) {
+    const long long i = (n4 << 2) + threadIdx.x;
+    const float v = y[base + i] > 0.f ? go[base + i] : 0.f;
+    g[base + i] = v;
+    s += v;
+  }
+  s = cp_wave_sum(s);
+  __shared__ float red[4];
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0 && gbias) atomicAdd(&gbias[bc % C], (red[0] + red[1]) + (red[2] + red[3]));
+}
+}  // namespace
+
+extern "C" int cp_bias_relu_backward(const float* y, const float* grad_out, float* grad_in,
+                                     float* grad_bias, int32_t B, int32_t C, int64_t HW,
+                                     void* stream) {
+  CP_CHECK_ARG(y && grad_out && grad_in && B > 0 && C > 0 && HW > 0);
+  if ((long long)B * C > 65535) return CP_EUNSUPPORTED;
+  if ((((uintptr_t)y) | ((uintptr_t)grad_out) | ((uintptr_t)grad_in)) & 15) return CP_EUNSUPPORTED;
+  if ((HW & 3) != 0) return CP_EUNSUPPORTED;
+  long long nb = ((HW >> 2) + 255) / 256;
+  if (nb > 64) nb = 64;
+  hipLaunchKernelGGL(bias_relu_bwd_kernel, dim3((unsigned)nb, B * C), dim3(256), 0, (hipStream_t)stream,
+                     y, grad_out, grad_in, grad_bias, C, (long long)HW);
+  return cp_launch_status();
+}
+
 // ------------------------------------------------- depth-wise up-sampling, backward ---
 // Training path of IDAUp's `up` (+ skip add): grad_skip = grad_out (identity, done by the
 // caller), grad_x = the stride-f depth-wise correlation of grad_out with the same 2f x 2f

@@ -67,6 +67,43 @@ def _conv_folded(x, conv, wb, relu=False, residual=None):
     return y
 
 
+# ---- training-time fused conv-bias + ReLU (the heads' Conv2d(3x3, bias) -> ReLU) -----------
+class _BiasRelu(torch.autograd.Function):
+    """y = relu(y_raw + bias[c]) in place on the convolution's raw output; backward is one pass
+    (mask + bias reduction) instead of threshold_backward and a separate bias sum."""
+
+    @staticmethod
+    def forward(ctx, y_raw, bias):
+        B, C, H, W = y_raw.shape
+        _C.check(_C.lib().cp_bias_act_inplace(_C.ptr(y_raw), _C.ptr(bias), None, B, C, H * W, 1, _C.stream()),
+                 "cp_bias_act_inplace")
+        ctx.mark_dirty(y_raw)
+        ctx.save_for_backward(y_raw)
+        return y_raw
+
+    @staticmethod
+    def backward(ctx, go):
+        (y,) = ctx.saved_tensors
+        go = go.contiguous()
+        B, C, H, W = y.shape
+        g = torch.empty_like(go)
+        gb = torch.zeros(C, dtype=torch.float32, device=y.device)
+        _C.check(_C.lib().cp_bias_relu_backward(_C.ptr(y), _C.ptr(go), _C.ptr(g), _C.ptr(gb), B, C, H * W,
+                                                _C.stream()), "cp_bias_relu_backward")
+        return g, gb
+
+
+def conv_bias_relu(conv, x):
+    """conv (with bias) followed by ReLU: fused epilogue on a HIP device in training."""
+    if (x.is_cuda and conv.bias is not None and x.dtype == torch.float32 and torch.is_grad_enabled()
+            and conv.groups == 1):
+        y = F.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation)
+        if y.is_contiguous() and (y.shape[2] * y.shape[3]) % 4 == 0 and y.shape[0] * y.shape[1] <= 65535:
+            return _BiasRelu.apply(y, conv.bias)
+        return F.relu(y + conv.bias.view(1, -1, 1, 1))
+    return F.relu(conv(x))
+
+
 # ---- training-time fused BatchNorm (+ residual) (+ ReLU) -------------------------------
 class _BnAct(torch.autograd.Function):
     @staticmethod
@@ -525,6 +562,10 @@ class DLASeg(nn.Module):
                 and not torch.is_grad_enabled() and y[-1].is_cuda \
                 and (y[-1].shape[2] * y[-1].shape[3]) % 4 == 0:
             return [self._heads_fast(y[-1])]
+        if self.training and y[-1].is_cuda and all(
+                isinstance(getattr(self, h), nn.Sequential) and len(getattr(self, h)) == 3 for h in self.heads):
+            # training: each head's Conv3x3 + bias + ReLU with the fused epilogue, then its 1x1 conv
+            return [{h: getattr(self, h)[2](conv_bias_relu(getattr(self, h)[0], y[-1])) for h in self.heads}]
         return [{head: getattr(self, head)(y[-1]) for head in self.heads}]
 
 

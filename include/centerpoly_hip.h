@@ -142,6 +142,12 @@ int cp_depthwise_up_backward(const float* x, const float* weight, const float* g
  * convolution whose BatchNorm was folded (inference).  bias / residual may be NULL. */
 int cp_bias_act_inplace(float* y, const float* bias, const float* residual, int32_t B, int32_t C,
                         int64_t HW, int32_t relu, void* stream);
+/* backward of y = relu(conv + bias[c]) (cp_bias_act_inplace with relu, no residual; the heads'
+ * Conv2d(3x3, bias) -> ReLU in training, src/lib/models/networks/pose_dla_dcn.py:448-451):
+ * grad_in = grad_out * [y > 0] (grad_in == grad_out allowed), grad_bias[c] is ACCUMULATED INTO
+ * (caller zero-fills).  HW % 4 == 0, 16-byte aligned tensors. */
+int cp_bias_relu_backward(const float* y, const float* grad_out, float* grad_in, float* grad_bias,
+                          int32_t B, int32_t C, int64_t HW, void* stream);
 
 /* Output stage of a detection head at inference (the `fc` Sequential of DLASeg,
  * src/lib/models/networks/pose_dla_dcn.py:445-462: Conv2d 3x3 + bias -> ReLU -> Conv2d 1x1 + bias),

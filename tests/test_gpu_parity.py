@@ -452,6 +452,25 @@ def test_head_output_stage_vs_torch(cin, cout, hw, relu):
                                            _C.stream()) == -2
 
 
+def test_conv_bias_relu_training_epilogue_vs_torch():
+    """Heads' Conv3x3(bias) -> ReLU in training: fused in-place epilogue + one-pass backward."""
+    from centerpoly_amd.models.networks.pose_dla_dcn import conv_bias_relu
+    torch.manual_seed(5)
+    conv = torch.nn.Conv2d(12, 20, 3, padding=1, bias=True).to(DEV)
+    x1 = g(synth.normal("cbr/x", (2, 12, 10, 16))).requires_grad_()
+    x2 = x1.detach().clone().requires_grad_()
+    go = g(synth.normal("cbr/go", (2, 20, 10, 16)))
+    y1 = conv_bias_relu(conv, x1)
+    y1.backward(go)
+    grads1 = (x1.grad.clone(), conv.weight.grad.clone(), conv.bias.grad.clone())
+    conv.zero_grad()
+    y2 = torch.relu(conv(x2))
+    y2.backward(go)
+    torch.testing.assert_close(y1, y2, rtol=1e-5, atol=1e-6)
+    for a, b in zip(grads1, (x2.grad, conv.weight.grad, conv.bias.grad)):
+        torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-5)
+
+
 def test_dcn_fused_bn_relu_epilogue():
     from centerpoly_amd.models.networks.pose_dla_dcn import DeformConv
     m = DeformConv(32, 64).to(DEV)
