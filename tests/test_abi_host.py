@@ -126,3 +126,18 @@ def test_post_process_mirror_matches_golden(golden):
     for j in range(1, C + 1):
         a = np.array(ret[0][j], dtype=np.float32).reshape(-1, 2 * N + 6)
         np.testing.assert_allclose(a, g["cls%d" % j], rtol=1e-6, atol=1e-4)
+
+
+def test_ctypes_signatures_match_header_arity():
+    """Every declaration of include/centerpoly_hip.h is bound in _C._SIGNATURES with the same
+    number of arguments (a drifted binding would corrupt the call instead of failing)."""
+    import re
+    from centerpoly_amd import _C
+    text = open(os.path.join(ROOT, "include", "centerpoly_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    decls = re.findall(r"\b(?:int|size_t|const char\*)\s+(cp_\w+)\s*\(([^;]*?)\)\s*;", text, flags=re.S)
+    assert len(decls) >= 30
+    for name, args in decls:
+        n = 0 if args.strip() in ("", "void") else len(args.split(","))
+        assert name in _C._SIGNATURES, name
+        assert len(_C._SIGNATURES[name][1]) == n, name
