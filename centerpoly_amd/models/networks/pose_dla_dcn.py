@@ -252,8 +252,8 @@ class Tree(nn.Module):
                     self.project(bottom)
         elif _use_folded(self):
             residual = _conv_folded(bottom, self.project[0], self._folded)
-        else:
-            residual = self.project(bottom)
+        else:                                  # conv1x1 + BatchNorm (no activation), fused BN in training
+            residual = bn_act(self.project[1], self.project[0](bottom), relu=False)
         if self.level_root:
             children.append(bottom)
         x1 = self.tree1(x, residual)
