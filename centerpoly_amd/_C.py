@@ -57,6 +57,7 @@ _SIGNATURES = {
     "cp_bn_act_backward": (c_int32, [_P] * 6 + [c_int32] + [_P] * 4 + [c_int32, c_int32, c_int64, _P,
                                                                        c_size_t, _P]),
     "cp_bias_act_inplace": (c_int32, [_P, _P, _P, c_int32, c_int32, c_int64, c_int32, _P]),
+    "cp_channel_sum_accumulate": (c_int32, [_P, _P, c_int32, c_int32, c_int64, _P]),
     "cp_bias_relu_backward": (c_int32, [_P, _P, _P, _P, c_int32, c_int32, c_int64, _P]),
     "cp_preprocess_warp_normalize": (c_int32, [_P, c_int32, c_int32, _P, _P, _P, c_int32, c_int32, c_int32, _P, _P]),
     "cp_polydet_post_process": (c_int32, [_P, _P, c_float, c_int32, c_int32, c_int32, _P, _P]),

@@ -973,3 +973,15 @@ extern "C" int cp_dcn_v2_backward(const cp_dcn_shape* s, const float* x, const f
   }
   return cp_launch_status();
 }
+
+// out[c] += sum_{b,p} x[b][c][p]: the bias gradient of a library convolution (the 27-channel
+// conv_offset_mask of every DCN; torch's generic reduction takes 148 us on [4,27,256,512]).
+extern "C" int cp_channel_sum_accumulate(const float* x, float* out, int32_t B, int32_t C, int64_t HW,
+                                         void* stream) {
+  CP_CHECK_ARG(x && out && B > 0 && C > 0 && HW > 0);
+  if (HW >= (1ll << 31) || C > 65535) return CP_EUNSUPPORTED;
+  const long long total = (long long)B * HW;
+  hipLaunchKernelGGL(dcn_bwd_bias_kernel, dim3(C, (unsigned)((total + BIAS_SEG - 1) / BIAS_SEG)), dim3(256), 0,
+                     (hipStream_t)stream, x, out, B, C, (int)HW);
+  return cp_launch_status();
+}

@@ -11,6 +11,7 @@ modulates and contracts on the matrix cores.  No chunk/cat/sigmoid/im2col tensor
 import math
 
 import torch
+import torch.nn.functional as F
 import torch.nn as nn
 from torch.nn.modules.utils import _pair
 
@@ -85,6 +86,40 @@ class _DCNv2Function(torch.autograd.Function):
         return gx, gom, gw, (gb if ctx.has_bias else None), None, None, None, None
 
 
+class _ConvBias(torch.autograd.Function):
+    """y_raw + bias[c] in place on a convolution's raw output; the bias gradient is one
+    segmented channel sum (cp_channel_sum_accumulate) instead of torch's generic reduction."""
+
+    @staticmethod
+    def forward(ctx, y_raw, bias):
+        B, C, H, W = y_raw.shape
+        _C.check(_C.lib().cp_bias_act_inplace(_C.ptr(y_raw), _C.ptr(bias), None, B, C, H * W, 0, _C.stream()),
+                 "cp_bias_act_inplace")
+        ctx.mark_dirty(y_raw)
+        return y_raw
+
+    @staticmethod
+    def backward(ctx, go):
+        go = go.contiguous()
+        B, C, H, W = go.shape
+        gb = torch.zeros(C, dtype=torch.float32, device=go.device)
+        _C.check(_C.lib().cp_channel_sum_accumulate(_C.ptr(go), _C.ptr(gb), B, C, H * W, _C.stream()),
+                 "cp_channel_sum_accumulate")
+        return go, gb
+
+
+def conv_bias(conv, x):
+    """conv with bias; in training on a HIP device the bias add / bias gradient are the fused
+    in-place epilogue and one channel-sum kernel."""
+    if x.is_cuda and conv.bias is not None and torch.is_grad_enabled() and x.dtype == torch.float32 \
+            and conv.groups == 1:
+        y = F.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation)
+        if y.is_contiguous() and (y.shape[2] * y.shape[3]) % 4 == 0 and y.shape[0] * y.shape[1] <= 65535:
+            return _ConvBias.apply(y, conv.bias)
+        return y + conv.bias.view(1, -1, 1, 1)
+    return conv(x)
+
+
 class DCN(nn.Module):
     """DCN(in_channels, out_channels, kernel_size, stride, padding, dilation=1,
     deformable_groups=1): forward(x[B,Cin,H,W]) -> [B,Cout,Ho,Wo]."""
@@ -118,7 +153,7 @@ class DCN(nn.Module):
             self.conv_offset_mask.bias.zero_()
 
     def forward(self, x):
-        om = self.conv_offset_mask(x)
+        om = conv_bias(self.conv_offset_mask, x)
         return _DCNv2Function.apply(x, om, self.weight, self.bias, self.stride, self.padding,
                                     self.dilation, self.deformable_groups)
 

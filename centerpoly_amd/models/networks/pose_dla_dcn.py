@@ -556,7 +556,9 @@ class DLASeg(nn.Module):
 
     def forward(self, x):
         x = self.dla_up(self.base(x))
-        y = [x[i].clone() for i in range(self.last_level - self.first_level)]
+        # (the reference clones these tensors, pose_dla_dcn.py:476-478; IDAUp here only re-binds list
+        #  entries and never writes into its inputs, so the copies are not needed)
+        y = [x[i] for i in range(self.last_level - self.first_level)]
         self.ida_up(y, 0, len(y))
         if getattr(self, "_heads_cat", None) is not None and not self.training \
                 and not torch.is_grad_enabled() and y[-1].is_cuda \

@@ -148,6 +148,9 @@ int cp_bias_act_inplace(float* y, const float* bias, const float* residual, int3
  * (caller zero-fills).  HW % 4 == 0, 16-byte aligned tensors. */
 int cp_bias_relu_backward(const float* y, const float* grad_out, float* grad_in, float* grad_bias,
                           int32_t B, int32_t C, int64_t HW, void* stream);
+/* out[c] += sum over images and pixels of x[b][c][p] (fp32 NCHW): the bias gradient of a library
+ * convolution (conv_offset_mask of DCN, src/lib/models/networks/pose_dla_dcn.py:354 via DCNv2). */
+int cp_channel_sum_accumulate(const float* x, float* out, int32_t B, int32_t C, int64_t HW, void* stream);
 
 /* Output stage of a detection head at inference (the `fc` Sequential of DLASeg,
  * src/lib/models/networks/pose_dla_dcn.py:445-462: Conv2d 3x3 + bias -> ReLU -> Conv2d 1x1 + bias),

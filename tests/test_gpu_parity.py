@@ -452,6 +452,25 @@ def test_head_output_stage_vs_torch(cin, cout, hw, relu):
                                            _C.stream()) == -2
 
 
+def test_conv_bias_training_epilogue_vs_torch():
+    """conv_offset_mask in training: in-place bias add + channel-sum bias gradient."""
+    from centerpoly_amd.models.networks.DCNv2.dcn_v2 import conv_bias
+    torch.manual_seed(6)
+    conv = torch.nn.Conv2d(10, 27, 3, padding=1, bias=True).to(DEV)
+    x1 = g(synth.normal("cb/x", (3, 10, 12, 20))).requires_grad_()
+    x2 = x1.detach().clone().requires_grad_()
+    go = g(synth.normal("cb/go", (3, 27, 12, 20)))
+    y1 = conv_bias(conv, x1)
+    (y1 * 1.0).backward(go)
+    grads1 = (x1.grad.clone(), conv.weight.grad.clone(), conv.bias.grad.clone())
+    conv.zero_grad()
+    y2 = conv(x2)
+    y2.backward(go)
+    torch.testing.assert_close(y1, y2, rtol=1e-5, atol=1e-6)
+    for a, b in zip(grads1, (x2.grad, conv.weight.grad, conv.bias.grad)):
+        torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-4)
+
+
 def test_conv_bias_relu_training_epilogue_vs_torch():
     """Heads' Conv3x3(bias) -> ReLU in training: fused in-place epilogue + one-pass backward."""
     from centerpoly_amd.models.networks.pose_dla_dcn import conv_bias_relu
