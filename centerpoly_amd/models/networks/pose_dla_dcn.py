@@ -18,7 +18,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from ... import _C
-from .DCNv2.dcn_v2 import DCN
+from .DCNv2.dcn_v2 import DCN, conv_bias
 
 BN_MOMENTUM = 0.1
 
@@ -567,7 +567,8 @@ class DLASeg(nn.Module):
         if self.training and y[-1].is_cuda and all(
                 isinstance(getattr(self, h), nn.Sequential) and len(getattr(self, h)) == 3 for h in self.heads):
             # training: each head's Conv3x3 + bias + ReLU with the fused epilogue, then its 1x1 conv
-            return [{h: getattr(self, h)[2](conv_bias_relu(getattr(self, h)[0], y[-1])) for h in self.heads}]
+            return [{h: conv_bias(getattr(self, h)[2], conv_bias_relu(getattr(self, h)[0], y[-1]))
+                     for h in self.heads}]
         return [{head: getattr(self, head)(y[-1]) for head in self.heads}]
 
 
