@@ -306,23 +306,40 @@ __global__ __launch_bounds__(256, WPS) void dcn_bwd_data_tiled_kernel(DcnBwdArgs
   const int Ktot = a.Cin * TAPS;
   const int ry0 = ty - RR, rx0 = tx0 - RR;
 
-  Recipe r;
-  build_recipe(a, b, p, p_ok, r);
-  // region offset of each tap's top-left corner, -1 when a corner leaves the region
+  // Slim per-tap recipe: bilinear fractions, mask, and ONE integer that is either the region
+  // offset of the tap's top-left corner (>= 0), -2 (contributes nothing), or, for a tap whose
+  // corners leave the region, -(3 + (clamped top-left index << 4 | corner validity bits)) --
+  // what the cold fallback path needs, without nine more registers in the hot loop.
+  float rly[TAPS], rlx[TAPS], rm[TAPS];
   int rbase[TAPS];
   {
     const float* off = a.offset + (long long)b * a.offset_bstride;
+    const float* msk = a.mask + (long long)b * a.mask_bstride;
 #pragma unroll
     for (int t = 0; t < TAPS; ++t) {
       const int ky = t / 3, kx = t - ky * 3;
-      const float py = (float)(ty * a.stride - a.pad + ky * a.dil) + off[(long long)(2 * t) * HWo + p];
-      const float px = (float)((tx0 + lane) * a.stride - a.pad + kx * a.dil) +
-                       off[(long long)(2 * t + 1) * HWo + p];
+      float oy = 0.f, ox = 0.f, m = 0.f;
+      if (p_ok) {
+        oy = off[(long long)(2 * t) * HWo + p];
+        ox = off[(long long)(2 * t + 1) * HWo + p];
+        m = msk[(long long)t * HWo + p];
+        if (a.mask_is_logit) m = 1.f / (1.f + __expf(-m));
+      }
+      const float py = (float)(ty * a.stride - a.pad + ky * a.dil) + oy;
+      const float px = (float)((tx0 + lane) * a.stride - a.pad + kx * a.dil) + ox;
       const bool inside = p_ok && py > -1.f && px > -1.f && py < (float)a.H && px < (float)a.W;
-      const int y0 = (int)floorf(py), x0 = (int)floorf(px);
+      const float fy = floorf(py), fx = floorf(px);
+      const int y0 = (int)fy, x0 = (int)fx;
+      rly[t] = py - fy;
+      rlx[t] = px - fx;
+      rm[t] = m;
+      const bool y0ok = y0 >= 0, y1ok = y0 + 1 <= a.H - 1;
+      const bool x0ok = x0 >= 0, x1ok = x0 + 1 <= a.W - 1;
+      const int y0c = min(max(y0, 0), a.H - 1), x0c = min(max(x0, 0), a.W - 1);
+      const int vb = (y0ok && x0ok ? 1 : 0) | (y0ok && x1ok ? 2 : 0) | (y1ok && x0ok ? 4 : 0) | (y1ok && x1ok ? 8 : 0);
       const int ry = y0 - ry0, rx = x0 - rx0;
-      rbase[t] = (inside && ry >= 0 && ry + 1 < RH && rx >= 0 && rx + 1 < RW) ? ry * RWP + rx
-                 : (inside ? -1 : -2);    // -2: contributes nothing at all
+      const bool in_region = inside && ry >= 0 && ry + 1 < RH && rx >= 0 && rx + 1 < RW;
+      rbase[t] = in_region ? ry * RWP + rx : (inside ? -(3 + (((y0c * a.W + x0c) << 4) | vb)) : -2);
     }
   }
   float gm[TAPS], gy[TAPS], gxo[TAPS];
@@ -447,26 +464,30 @@ __global__ __launch_bounds__(256, WPS) void dcn_bwd_data_tiled_kernel(DcnBwdArgs
 #pragma unroll
       for (int t = 0; t < TAPS; ++t) {
         int rb = rbase[t];
-        if (CP_ABL(16) && rb == -1) rb = -2;
+        if (CP_ABL(16) && rb <= -3) rb = -2;
         if (rb == -2) continue;
         float v00, v01, v10, v11;
-        const unsigned vb = corner_bits(r, t);
-        const int dx = (r.step >> (2 * t)) & 1;
-        const int dy = ((r.step >> (2 * t + 1)) & 1) ? a.W : 0;
+        // fallback decode (rb <= -3): clamped top-left index and the corner validity bits; a
+        // column / row step exists when some row / column has both of its corners valid
+        const int code = -rb - 3;
+        const unsigned vb = rb <= -3 ? (unsigned)(code & 15) : 0u;
+        const int fbase = code >> 4;
+        const int dx = ((vb & 3u) == 3u || (vb & 12u) == 12u) ? 1 : 0;
+        const int dy = ((vb & 5u) == 5u || (vb & 10u) == 10u) ? a.W : 0;
         if (rb >= 0) {                     // out-of-image cells of the region hold 0
           v00 = xw[rb]; v01 = xw[rb + 1]; v10 = xw[rb + RWP]; v11 = xw[rb + RWP + 1];
         } else {
-          const float* q = xc + r.base[t];
+          const float* q = xc + fbase;
           v00 = (vb & 1u) ? q[0] : 0.f;
           v01 = (vb & 2u) ? q[dx] : 0.f;
           v10 = (vb & 4u) ? q[dy] : 0.f;
           v11 = (vb & 8u) ? q[dy + dx] : 0.f;
         }
-        const float ly = r.ly[t], lx = r.lx[t], hy = 1.f - ly, hx = 1.f - lx;
+        const float ly = rly[t], lx = rlx[t], hy = 1.f - ly, hx = 1.f - lx;
         const float gc = gcT[lane * LDG + wid * TAPS + t];
         const float val = hy * hx * v00 + hy * lx * v01 + ly * hx * v10 + ly * lx * v11;
         gm[t] += gc * val;
-        const float gcm = gc * r.m[t];
+        const float gcm = gc * rm[t];
         gy[t] += gcm * (hx * (v10 - v00) + lx * (v11 - v01));
         gxo[t] += gcm * (hy * (v01 - v00) + ly * (v11 - v10));
         if (gxb) {
@@ -477,7 +498,7 @@ __global__ __launch_bounds__(256, WPS) void dcn_bwd_data_tiled_kernel(DcnBwdArgs
             atomicAdd(&gw_[rb + RWP], fx_from_float(gs * (ly * hx)));
             atomicAdd(&gw_[rb + RWP + 1], fx_from_float(gs * (ly * lx)));
           } else if (vb) {
-            float* q = gxb + (long long)c * HW + r.base[t];
+            float* q = gxb + (long long)c * HW + fbase;
             if (vb & 1u) atomicAdd(q, gcm * hy * hx);
             if (vb & 2u) atomicAdd(q + dx, gcm * hy * lx);
             if (vb & 4u) atomicAdd(q + dy, gcm * ly * hx);
@@ -511,7 +532,7 @@ __global__ __launch_bounds__(256, WPS) void dcn_bwd_data_tiled_kernel(DcnBwdArgs
     red[(wid * 27 + 9 + t) * 64 + lane] = gxo[t];
     // (mask-logit chain rule applied here with a STATIC tap index: a runtime-indexed read of
     // the recipe would push the whole struct to scratch memory)
-    red[(wid * 27 + 18 + t) * 64 + lane] = a.mask_is_logit ? gm[t] * r.m[t] * (1.f - r.m[t]) : gm[t];
+    red[(wid * 27 + 18 + t) * 64 + lane] = a.mask_is_logit ? gm[t] * rm[t] * (1.f - rm[t]) : gm[t];
   }
   __syncthreads();
   for (int q = wid; q < 27; q += 4) {
@@ -928,7 +949,8 @@ extern "C" int cp_dcn_v2_backward(const cp_dcn_shape* s, const float* x, const f
   a.tpr = (s->W + BM - 1) / BM;
   const int row_tiles = s->H * a.tpr;       // tiled kernels: tiles never straddle rows
   const bool same_size = s->stride == 1 && Wo == s->W && Ho == s->H &&
-                         (unsigned long long)s->Cout * Ho * Wo * 4ull < 0xE0000000ull;
+                         (unsigned long long)s->Cout * Ho * Wo * 4ull < 0xE0000000ull &&
+                         (long long)s->H * s->W < (1ll << 27);     // fallback index packed with 4 bits
   if (grad_x || grad_offset || grad_mask) {
     const bool tiled = s->Cout <= 256 && same_size;
     if (tiled) {
