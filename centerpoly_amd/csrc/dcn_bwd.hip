@@ -342,6 +342,9 @@ __global__ __launch_bounds__(256, WPS) void dcn_bwd_data_tiled_kernel(DcnBwdArgs
       rbase[t] = in_region ? ry * RWP + rx : (inside ? -(3 + (((y0c * a.W + x0c) << 4) | vb)) : -2);
     }
   }
+  bool any_fallback = false;
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t) any_fallback |= rbase[t] <= -3;
   float gm[TAPS], gy[TAPS], gxo[TAPS];
 #pragma unroll
   for (int t = 0; t < TAPS; ++t) gm[t] = gy[t] = gxo[t] = 0.f;
@@ -458,51 +461,60 @@ __global__ __launch_bounds__(256, WPS) void dcn_bwd_data_tiled_kernel(DcnBwdArgs
     // ---- consumption: wave w handles channel c0 + w ----
     const int c = c0 + wid;
     if (c < a.Cin && !CP_ABL(1) && gmax > 0.f) {
-      const float* xc = xb + (long long)c * HW;
       const float* xw = xreg + wid * RSZ;
       unsigned long long* gw_ = greg + wid * RSZ;
+      // hot loop: taps served by the LDS region (one divergent `if`, no fallback state live)
 #pragma unroll
       for (int t = 0; t < TAPS; ++t) {
-        int rb = rbase[t];
-        if (CP_ABL(16) && rb <= -3) rb = -2;
-        if (rb == -2) continue;
-        float v00, v01, v10, v11;
-        // fallback decode (rb <= -3): clamped top-left index and the corner validity bits; a
-        // column / row step exists when some row / column has both of its corners valid
-        const int code = -rb - 3;
-        const unsigned vb = rb <= -3 ? (unsigned)(code & 15) : 0u;
-        const int fbase = code >> 4;
-        const int dx = ((vb & 3u) == 3u || (vb & 12u) == 12u) ? 1 : 0;
-        const int dy = ((vb & 5u) == 5u || (vb & 10u) == 10u) ? a.W : 0;
+        const int rb = rbase[t];
         if (rb >= 0) {                     // out-of-image cells of the region hold 0
-          v00 = xw[rb]; v01 = xw[rb + 1]; v10 = xw[rb + RWP]; v11 = xw[rb + RWP + 1];
-        } else {
-          const float* q = xc + fbase;
-          v00 = (vb & 1u) ? q[0] : 0.f;
-          v01 = (vb & 2u) ? q[dx] : 0.f;
-          v10 = (vb & 4u) ? q[dy] : 0.f;
-          v11 = (vb & 8u) ? q[dy + dx] : 0.f;
-        }
-        const float ly = rly[t], lx = rlx[t], hy = 1.f - ly, hx = 1.f - lx;
-        const float gc = gcT[lane * LDG + wid * TAPS + t];
-        const float val = hy * hx * v00 + hy * lx * v01 + ly * hx * v10 + ly * lx * v11;
-        gm[t] += gc * val;
-        const float gcm = gc * rm[t];
-        gy[t] += gcm * (hx * (v10 - v00) + lx * (v11 - v01));
-        gxo[t] += gcm * (hy * (v01 - v00) + ly * (v11 - v10));
-        if (gxb) {
-          if (rb >= 0) {                   // cells outside the image are dropped at the flush
+          const float v00 = xw[rb], v01 = xw[rb + 1], v10 = xw[rb + RWP], v11 = xw[rb + RWP + 1];
+          const float ly = rly[t], lx = rlx[t], hy = 1.f - ly, hx = 1.f - lx;
+          const float gc = gcT[lane * LDG + wid * TAPS + t];
+          gm[t] += gc * (hy * hx * v00 + hy * lx * v01 + ly * hx * v10 + ly * lx * v11);
+          const float gcm = gc * rm[t];
+          gy[t] += gcm * (hx * (v10 - v00) + lx * (v11 - v01));
+          gxo[t] += gcm * (hy * (v01 - v00) + ly * (v11 - v10));
+          if (gxb) {                       // cells outside the image are dropped at the flush
             const float gs = gcm * fx_scale;
             atomicAdd(&gw_[rb], fx_from_float(gs * (hy * hx)));
             atomicAdd(&gw_[rb + 1], fx_from_float(gs * (hy * lx)));
             atomicAdd(&gw_[rb + RWP], fx_from_float(gs * (ly * hx)));
             atomicAdd(&gw_[rb + RWP + 1], fx_from_float(gs * (ly * lx)));
-          } else if (vb) {
-            float* q = gxb + (long long)c * HW + fbase;
-            if (vb & 1u) atomicAdd(q, gcm * hy * hx);
-            if (vb & 2u) atomicAdd(q + dx, gcm * hy * lx);
-            if (vb & 4u) atomicAdd(q + dy, gcm * ly * hx);
-            if (vb & 8u) atomicAdd(q + dy + dx, gcm * ly * lx);
+          }
+        }
+      }
+      // cold loop (skipped wave-uniformly when no lane of the tile has such a tap): corners that
+      // leave the region go to memory.  rb <= -3 packs the clamped top-left index and the corner
+      // validity bits; a column / row step exists when some row / column has both corners valid.
+      if (__builtin_amdgcn_ballot_w64(any_fallback) != 0ull && !CP_ABL(16)) {
+        const float* xc = xb + (long long)c * HW;
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t) {
+          const int rb = rbase[t];
+          if (rb > -3) continue;
+          const int code = -rb - 3;
+          const unsigned vb = (unsigned)(code & 15);
+          const int fbase = code >> 4;
+          const int dx = ((vb & 3u) == 3u || (vb & 12u) == 12u) ? 1 : 0;
+          const int dy = ((vb & 5u) == 5u || (vb & 10u) == 10u) ? a.W : 0;
+          const float* q = xc + fbase;
+          const float v00 = (vb & 1u) ? q[0] : 0.f;
+          const float v01 = (vb & 2u) ? q[dx] : 0.f;
+          const float v10 = (vb & 4u) ? q[dy] : 0.f;
+          const float v11 = (vb & 8u) ? q[dy + dx] : 0.f;
+          const float ly = rly[t], lx = rlx[t], hy = 1.f - ly, hx = 1.f - lx;
+          const float gc = gcT[lane * LDG + wid * TAPS + t];
+          gm[t] += gc * (hy * hx * v00 + hy * lx * v01 + ly * hx * v10 + ly * lx * v11);
+          const float gcm = gc * rm[t];
+          gy[t] += gcm * (hx * (v10 - v00) + lx * (v11 - v01));
+          gxo[t] += gcm * (hy * (v01 - v00) + ly * (v11 - v10));
+          if (gxb && vb) {
+            float* g = gxb + (long long)c * HW + fbase;
+            if (vb & 1u) atomicAdd(g, gcm * hy * hx);
+            if (vb & 2u) atomicAdd(g + dx, gcm * hy * lx);
+            if (vb & 4u) atomicAdd(g + dy, gcm * ly * hx);
+            if (vb & 8u) atomicAdd(g + dy + dx, gcm * ly * lx);
           }
         }
       }
