@@ -277,6 +277,55 @@ constexpr int RW = BM + 2 * RR + 1;      // 71 columns
 constexpr int RWP = 72;                  // padded row
 constexpr int RSZ = RH * RWP;            // 576 floats per channel
 
+// Slim per-tap recipe of the LDS-region kernels: bilinear fractions, mask, and ONE integer that is
+// either the region offset of the tap's top-left corner (>= 0), -2 (contributes nothing), or, for
+// a tap whose corners leave the region, -(3 + (clamped top-left index << 4 | corner validity
+// bits)) -- what the cold fallback path needs, without nine more registers in the hot loop.
+__device__ __forceinline__ void slim_recipe(const DcnBwdArgs& a, int b, int p, bool p_ok, int ty, int tx0,
+                                            int lane, float (&rly)[TAPS], float (&rlx)[TAPS],
+                                            float (&rm)[TAPS], int (&rbase)[TAPS]) {
+  const int HWo = a.Ho * a.Wo;
+  const int ry0 = ty - RR, rx0 = tx0 - RR;
+  const float* off = a.offset + (long long)b * a.offset_bstride;
+  const float* msk = a.mask + (long long)b * a.mask_bstride;
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t) {
+    const int ky = t / 3, kx = t - ky * 3;
+    float oy = 0.f, ox = 0.f, m = 0.f;
+    if (p_ok) {
+      oy = off[(long long)(2 * t) * HWo + p];
+      ox = off[(long long)(2 * t + 1) * HWo + p];
+      m = msk[(long long)t * HWo + p];
+      if (a.mask_is_logit) m = 1.f / (1.f + __expf(-m));
+    }
+    const float py = (float)(ty * a.stride - a.pad + ky * a.dil) + oy;
+    const float px = (float)((tx0 + lane) * a.stride - a.pad + kx * a.dil) + ox;
+    const bool inside = p_ok && py > -1.f && px > -1.f && py < (float)a.H && px < (float)a.W;
+    const float fy = floorf(py), fx = floorf(px);
+    const int y0 = (int)fy, x0 = (int)fx;
+    rly[t] = py - fy;
+    rlx[t] = px - fx;
+    rm[t] = m;
+    const bool y0ok = y0 >= 0, y1ok = y0 + 1 <= a.H - 1;
+    const bool x0ok = x0 >= 0, x1ok = x0 + 1 <= a.W - 1;
+    const int y0c = min(max(y0, 0), a.H - 1), x0c = min(max(x0, 0), a.W - 1);
+    const int vb = (y0ok && x0ok ? 1 : 0) | (y0ok && x1ok ? 2 : 0) | (y1ok && x0ok ? 4 : 0) | (y1ok && x1ok ? 8 : 0);
+    const int ry = y0 - ry0, rx = x0 - rx0;
+    const bool in_region = inside && ry >= 0 && ry + 1 < RH && rx >= 0 && rx + 1 < RW;
+    rbase[t] = in_region ? ry * RWP + rx : (inside ? -(3 + (((y0c * a.W + x0c) << 4) | vb)) : -2);
+  }
+}
+
+// Decode of a fallback tap (rb <= -3): clamped top-left index, validity bits, and the column / row
+// steps (a step exists when some row / column has both of its corners valid).
+__device__ __forceinline__ void fallback_decode(int rb, int W, int& fbase, unsigned& vb, int& dx, int& dy) {
+  const int code = -rb - 3;
+  vb = (unsigned)(code & 15);
+  fbase = code >> 4;
+  dx = ((vb & 3u) == 3u || (vb & 12u) == 12u) ? 1 : 0;
+  dy = ((vb & 5u) == 5u || (vb & 10u) == 10u) ? W : 0;
+}
+
 template <int CP, int WPS>                // Cout rounded up to 64/128/256; waves per SIMD
 __global__ __launch_bounds__(256, WPS) void dcn_bwd_data_tiled_kernel(DcnBwdArgs a) {
   constexpr int LDO = CP + 1;
@@ -306,42 +355,9 @@ __global__ __launch_bounds__(256, WPS) void dcn_bwd_data_tiled_kernel(DcnBwdArgs
   const int Ktot = a.Cin * TAPS;
   const int ry0 = ty - RR, rx0 = tx0 - RR;
 
-  // Slim per-tap recipe: bilinear fractions, mask, and ONE integer that is either the region
-  // offset of the tap's top-left corner (>= 0), -2 (contributes nothing), or, for a tap whose
-  // corners leave the region, -(3 + (clamped top-left index << 4 | corner validity bits)) --
-  // what the cold fallback path needs, without nine more registers in the hot loop.
   float rly[TAPS], rlx[TAPS], rm[TAPS];
   int rbase[TAPS];
-  {
-    const float* off = a.offset + (long long)b * a.offset_bstride;
-    const float* msk = a.mask + (long long)b * a.mask_bstride;
-#pragma unroll
-    for (int t = 0; t < TAPS; ++t) {
-      const int ky = t / 3, kx = t - ky * 3;
-      float oy = 0.f, ox = 0.f, m = 0.f;
-      if (p_ok) {
-        oy = off[(long long)(2 * t) * HWo + p];
-        ox = off[(long long)(2 * t + 1) * HWo + p];
-        m = msk[(long long)t * HWo + p];
-        if (a.mask_is_logit) m = 1.f / (1.f + __expf(-m));
-      }
-      const float py = (float)(ty * a.stride - a.pad + ky * a.dil) + oy;
-      const float px = (float)((tx0 + lane) * a.stride - a.pad + kx * a.dil) + ox;
-      const bool inside = p_ok && py > -1.f && px > -1.f && py < (float)a.H && px < (float)a.W;
-      const float fy = floorf(py), fx = floorf(px);
-      const int y0 = (int)fy, x0 = (int)fx;
-      rly[t] = py - fy;
-      rlx[t] = px - fx;
-      rm[t] = m;
-      const bool y0ok = y0 >= 0, y1ok = y0 + 1 <= a.H - 1;
-      const bool x0ok = x0 >= 0, x1ok = x0 + 1 <= a.W - 1;
-      const int y0c = min(max(y0, 0), a.H - 1), x0c = min(max(x0, 0), a.W - 1);
-      const int vb = (y0ok && x0ok ? 1 : 0) | (y0ok && x1ok ? 2 : 0) | (y1ok && x0ok ? 4 : 0) | (y1ok && x1ok ? 8 : 0);
-      const int ry = y0 - ry0, rx = x0 - rx0;
-      const bool in_region = inside && ry >= 0 && ry + 1 < RH && rx >= 0 && rx + 1 < RW;
-      rbase[t] = in_region ? ry * RWP + rx : (inside ? -(3 + (((y0c * a.W + x0c) << 4) | vb)) : -2);
-    }
-  }
+  slim_recipe(a, b, p, p_ok, ty, tx0, lane, rly, rlx, rm, rbase);
   bool any_fallback = false;
 #pragma unroll
   for (int t = 0; t < TAPS; ++t) any_fallback |= rbase[t] <= -3;
@@ -493,11 +509,9 @@ __global__ __launch_bounds__(256, WPS) void dcn_bwd_data_tiled_kernel(DcnBwdArgs
         for (int t = 0; t < TAPS; ++t) {
           const int rb = rbase[t];
           if (rb > -3) continue;
-          const int code = -rb - 3;
-          const unsigned vb = (unsigned)(code & 15);
-          const int fbase = code >> 4;
-          const int dx = ((vb & 3u) == 3u || (vb & 12u) == 12u) ? 1 : 0;
-          const int dy = ((vb & 5u) == 5u || (vb & 10u) == 10u) ? a.W : 0;
+          int fbase, dx, dy;
+          unsigned vb;
+          fallback_decode(rb, a.W, fbase, vb, dx, dy);
           const float* q = xc + fbase;
           const float v00 = (vb & 1u) ? q[0] : 0.f;
           const float v01 = (vb & 2u) ? q[dx] : 0.f;
@@ -730,27 +744,12 @@ __global__ __launch_bounds__(256, WPS) void dcn_bwd_weight_tiled_kernel(DcnBwdAr
     const bool p_ok = tx0 + lane < a.W;     // partial last tile of a row when W % 64 != 0
     const int p = p_ok ? p0 + lane : p0;
     const int ry0 = ty - RR, rx0 = tx0 - RR;
-    Recipe r;
-    build_recipe(a, b, p, p_ok, r);
+    float rly[TAPS], rlx[TAPS], rm[TAPS];
     int rbase[TAPS];
-    {
-      const float* off = a.offset + (long long)b * a.offset_bstride;
-#pragma unroll
-      for (int t = 0; t < TAPS; ++t) {
-        const int ky = t / 3, kx = t - ky * 3;
-        const float py = (float)(ty * a.stride - a.pad + ky * a.dil) + off[(long long)(2 * t) * HWo + p];
-        const float px = (float)((tx0 + lane) * a.stride - a.pad + kx * a.dil) +
-                         off[(long long)(2 * t + 1) * HWo + p];
-        const bool inside = p_ok && py > -1.f && px > -1.f && py < (float)a.H && px < (float)a.W;
-        const int y0 = (int)floorf(py), x0 = (int)floorf(px);
-        const int ry = y0 - ry0, rx = x0 - rx0;
-        rbase[t] = (inside && ry >= 0 && ry + 1 < RH && rx >= 0 && rx + 1 < RW) ? ry * RWP + rx
-                   : (inside ? -1 : -2);
-      }
-    }
+    slim_recipe(a, b, p, p_ok, ty, tx0, lane, rly, rlx, rm, rbase);
     bool any_fallback = false;
 #pragma unroll
-    for (int t = 0; t < TAPS; ++t) any_fallback |= rbase[t] == -1;
+    for (int t = 0; t < TAPS; ++t) any_fallback |= rbase[t] <= -3;
     unsigned roff[RPW];                    // this wave's region cells (channel c0 + w), per tile
 #pragma unroll
     for (int i = 0; i < RPW; ++i) {
@@ -807,8 +806,8 @@ __global__ __launch_bounds__(256, WPS) void dcn_bwd_weight_tiled_kernel(DcnBwdAr
         }
 #pragma unroll
         for (int t = 0; t < TAPS; ++t) {
-          const float ly = r.ly[t], lx = r.lx[t], hy = 1.f - ly, hx = 1.f - lx;
-          const float val = (hy * hx * v[t][0] + hy * lx * v[t][1] + ly * hx * v[t][2] + ly * lx * v[t][3]) * r.m[t];
+          const float ly = rly[t], lx = rlx[t], hy = 1.f - ly, hx = 1.f - lx;
+          const float val = (hy * hx * v[t][0] + hy * lx * v[t][1] + ly * hx * v[t][2] + ly * lx * v[t][3]) * rm[t];
           colT[lane * LDW2 + wid * TAPS + t] = (rbase[t] >= 0 && c_ok) ? val : 0.f;
         }
         // cold pass (wave-uniform skip): taps whose corners leave the region gather from memory
@@ -816,18 +815,18 @@ __global__ __launch_bounds__(256, WPS) void dcn_bwd_weight_tiled_kernel(DcnBwdAr
           const float* xc = xb + (long long)c * HW;
 #pragma unroll
           for (int t = 0; t < TAPS; ++t) {
-            if (rbase[t] != -1) continue;
-            const unsigned vb = corner_bits(r, t);
-            const int dx = (r.step >> (2 * t)) & 1;
-            const int dy = ((r.step >> (2 * t + 1)) & 1) ? a.W : 0;
-            const float* q = xc + r.base[t];
+            if (rbase[t] > -3) continue;
+            int fbase, dx, dy;
+            unsigned vb;
+            fallback_decode(rbase[t], a.W, fbase, vb, dx, dy);
+            const float* q = xc + fbase;
             const float v00 = (vb & 1u) ? q[0] : 0.f;
             const float v01 = (vb & 2u) ? q[dx] : 0.f;
             const float v10 = (vb & 4u) ? q[dy] : 0.f;
             const float v11 = (vb & 8u) ? q[dy + dx] : 0.f;
-            const float ly = r.ly[t], lx = r.lx[t], hy = 1.f - ly, hx = 1.f - lx;
+            const float ly = rly[t], lx = rlx[t], hy = 1.f - ly, hx = 1.f - lx;
             colT[lane * LDW2 + wid * TAPS + t] =
-                (hy * hx * v00 + hy * lx * v01 + ly * hx * v10 + ly * lx * v11) * r.m[t];
+                (hy * hx * v00 + hy * lx * v01 + ly * hx * v10 + ly * lx * v11) * rm[t];
           }
         }
       }
@@ -846,17 +845,17 @@ __global__ __launch_bounds__(256, WPS) void dcn_bwd_weight_tiled_kernel(DcnBwdAr
             if (rb >= 0) {
               v00 = xw[rb]; v01 = xw[rb + 1]; v10 = xw[rb + RWP]; v11 = xw[rb + RWP + 1];
             } else {
-              const unsigned vb = corner_bits(r, t);
-              const int dx = (r.step >> (2 * t)) & 1;
-              const int dy = ((r.step >> (2 * t + 1)) & 1) ? a.W : 0;
-              const float* q = xc + r.base[t];
+              int fbase, dx, dy;
+              unsigned vb;
+              fallback_decode(rb, a.W, fbase, vb, dx, dy);
+              const float* q = xc + fbase;
               v00 = (vb & 1u) ? q[0] : 0.f;
               v01 = (vb & 2u) ? q[dx] : 0.f;
               v10 = (vb & 4u) ? q[dy] : 0.f;
               v11 = (vb & 8u) ? q[dy + dx] : 0.f;
             }
-            const float ly = r.ly[t], lx = r.lx[t], hy = 1.f - ly, hx = 1.f - lx;
-            val = (hy * hx * v00 + hy * lx * v01 + ly * hx * v10 + ly * lx * v11) * r.m[t];
+            const float ly = rly[t], lx = rlx[t], hy = 1.f - ly, hx = 1.f - lx;
+            val = (hy * hx * v00 + hy * lx * v01 + ly * hx * v10 + ly * lx * v11) * rm[t];
           }
           colT[lane * LDW2 + wid * TAPS + t] = val;
         }
