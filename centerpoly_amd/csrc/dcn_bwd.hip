@@ -831,33 +831,38 @@ __global__ __launch_bounds__(256, WPS) void dcn_bwd_weight_tiled_kernel(DcnBwdAr
         }
       }
       else
-      {
+      {                                   // per-tap form, fallback taps in a wave-uniformly skipped loop
         const int c = c0 + wid;
         const bool c_ok = c < a.Cin;
-        const float* xc = xb + (long long)(c_ok ? c : 0) * HW;
         const float* xw = xreg + wid * RSZ;
 #pragma unroll
         for (int t = 0; t < TAPS; ++t) {
           const int rb = rbase[t];
           float val = 0.f;
-          if (rb != -2 && c_ok) {
-            float v00, v01, v10, v11;
-            if (rb >= 0) {
-              v00 = xw[rb]; v01 = xw[rb + 1]; v10 = xw[rb + RWP]; v11 = xw[rb + RWP + 1];
-            } else {
-              int fbase, dx, dy;
-              unsigned vb;
-              fallback_decode(rb, a.W, fbase, vb, dx, dy);
-              const float* q = xc + fbase;
-              v00 = (vb & 1u) ? q[0] : 0.f;
-              v01 = (vb & 2u) ? q[dx] : 0.f;
-              v10 = (vb & 4u) ? q[dy] : 0.f;
-              v11 = (vb & 8u) ? q[dy + dx] : 0.f;
-            }
+          if (rb >= 0 && c_ok) {
+            const float v00 = xw[rb], v01 = xw[rb + 1], v10 = xw[rb + RWP], v11 = xw[rb + RWP + 1];
             const float ly = rly[t], lx = rlx[t], hy = 1.f - ly, hx = 1.f - lx;
             val = (hy * hx * v00 + hy * lx * v01 + ly * hx * v10 + ly * lx * v11) * rm[t];
           }
           colT[lane * LDW2 + wid * TAPS + t] = val;
+        }
+        if (c_ok && __builtin_amdgcn_ballot_w64(any_fallback) != 0ull) {
+          const float* xc = xb + (long long)c * HW;
+#pragma unroll
+          for (int t = 0; t < TAPS; ++t) {
+            if (rbase[t] > -3) continue;
+            int fbase, dx, dy;
+            unsigned vb;
+            fallback_decode(rbase[t], a.W, fbase, vb, dx, dy);
+            const float* q = xc + fbase;
+            const float v00 = (vb & 1u) ? q[0] : 0.f;
+            const float v01 = (vb & 2u) ? q[dx] : 0.f;
+            const float v10 = (vb & 4u) ? q[dy] : 0.f;
+            const float v11 = (vb & 8u) ? q[dy + dx] : 0.f;
+            const float ly = rly[t], lx = rlx[t], hy = 1.f - ly, hx = 1.f - lx;
+            colT[lane * LDW2 + wid * TAPS + t] =
+                (hy * hx * v00 + hy * lx * v01 + ly * hx * v10 + ly * lx * v11) * rm[t];
+          }
         }
       }
       __syncthreads();
