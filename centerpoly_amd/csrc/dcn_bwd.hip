@@ -281,25 +281,31 @@ constexpr int RSZ = RH * RWP;            // 576 floats per channel
 // either the region offset of the tap's top-left corner (>= 0), -2 (contributes nothing), or, for
 // a tap whose corners leave the region, -(3 + (clamped top-left index << 4 | corner validity
 // bits)) -- what the cold fallback path needs, without nine more registers in the hot loop.
-__device__ __forceinline__ void slim_recipe(const DcnBwdArgs& a, int b, int p, bool p_ok, int ty, int tx0,
-                                            int lane, float (&rly)[TAPS], float (&rlx)[TAPS],
-                                            float (&rm)[TAPS], int (&rbase)[TAPS]) {
+__device__ __forceinline__ void slim_recipe_load(const DcnBwdArgs& a, int b, int p, bool p_ok,
+                                                 float (&raw)[3 * TAPS]) {
   const int HWo = a.Ho * a.Wo;
-  const int ry0 = ty - RR, rx0 = tx0 - RR;
   const float* off = a.offset + (long long)b * a.offset_bstride;
   const float* msk = a.mask + (long long)b * a.mask_bstride;
 #pragma unroll
   for (int t = 0; t < TAPS; ++t) {
+    raw[3 * t] = p_ok ? off[(long long)(2 * t) * HWo + p] : 0.f;
+    raw[3 * t + 1] = p_ok ? off[(long long)(2 * t + 1) * HWo + p] : 0.f;
+    raw[3 * t + 2] = p_ok ? msk[(long long)t * HWo + p] : 0.f;
+  }
+}
+
+__device__ __forceinline__ void slim_recipe_build(const DcnBwdArgs& a, bool p_ok, int ty, int tx0, int lane,
+                                                  const float (&raw)[3 * TAPS], float (&rly)[TAPS],
+                                                  float (&rlx)[TAPS], float (&rm)[TAPS], int (&rbase)[TAPS]) {
+  const int ry0 = ty - RR, rx0 = tx0 - RR;
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t) {
     const int ky = t / 3, kx = t - ky * 3;
-    float oy = 0.f, ox = 0.f, m = 0.f;
-    if (p_ok) {
-      oy = off[(long long)(2 * t) * HWo + p];
-      ox = off[(long long)(2 * t + 1) * HWo + p];
-      m = msk[(long long)t * HWo + p];
-      if (a.mask_is_logit) m = 1.f / (1.f + __expf(-m));
-    }
-    const float py = (float)(ty * a.stride - a.pad + ky * a.dil) + oy;
-    const float px = (float)((tx0 + lane) * a.stride - a.pad + kx * a.dil) + ox;
+    float m = raw[3 * t + 2];
+    if (a.mask_is_logit) m = 1.f / (1.f + __expf(-m));
+    if (!p_ok) m = 0.f;
+    const float py = (float)(ty * a.stride - a.pad + ky * a.dil) + raw[3 * t];
+    const float px = (float)((tx0 + lane) * a.stride - a.pad + kx * a.dil) + raw[3 * t + 1];
     const bool inside = p_ok && py > -1.f && px > -1.f && py < (float)a.H && px < (float)a.W;
     const float fy = floorf(py), fx = floorf(px);
     const int y0 = (int)fy, x0 = (int)fx;
@@ -314,6 +320,14 @@ __device__ __forceinline__ void slim_recipe(const DcnBwdArgs& a, int b, int p, b
     const bool in_region = inside && ry >= 0 && ry + 1 < RH && rx >= 0 && rx + 1 < RW;
     rbase[t] = in_region ? ry * RWP + rx : (inside ? -(3 + (((y0c * a.W + x0c) << 4) | vb)) : -2);
   }
+}
+
+__device__ __forceinline__ void slim_recipe(const DcnBwdArgs& a, int b, int p, bool p_ok, int ty, int tx0,
+                                            int lane, float (&rly)[TAPS], float (&rlx)[TAPS],
+                                            float (&rm)[TAPS], int (&rbase)[TAPS]) {
+  float raw[3 * TAPS];
+  slim_recipe_load(a, b, p, p_ok, raw);
+  slim_recipe_build(a, p_ok, ty, tx0, lane, raw, rly, rlx, rm, rbase);
 }
 
 // Decode of a fallback tap (rb <= -3): clamped top-left index, validity bits, and the column / row
@@ -738,15 +752,35 @@ __global__ __launch_bounds__(256, WPS) void dcn_bwd_weight_tiled_kernel(DcnBwdAr
   }
 
   const int t_begin = grp * ex.T, t_end = min(tiles, t_begin + ex.T);
+  // the 64 slab has the registers to fetch the NEXT tile's offsets / mask while this tile is
+  // processed (27 loads whose latency otherwise opens every tile)
+  constexpr bool PREFETCH = SLAB == 64;
+  float raw[3 * TAPS];
+  auto tile_geom = [&](int tile, int& ty, int& tx0, int& p, bool& p_ok) {
+    ty = tile / a.tpr;
+    tx0 = (tile - ty * a.tpr) * BM;
+    p_ok = tx0 + lane < a.W;                // partial last tile of a row when W % 64 != 0
+    p = ty * a.W + tx0 + (p_ok ? lane : 0);
+  };
+  if (PREFETCH && t_begin < t_end) {
+    int ty, tx0, p; bool p_ok;
+    tile_geom(t_begin, ty, tx0, p, p_ok);
+    slim_recipe_load(a, b, p, p_ok, raw);
+  }
   for (int tile = t_begin; tile < t_end; ++tile) {
-    const int ty = tile / a.tpr, tx0 = (tile - ty * a.tpr) * BM;
+    int ty, tx0, p; bool p_ok;
+    tile_geom(tile, ty, tx0, p, p_ok);
     const int p0 = ty * a.W + tx0;
-    const bool p_ok = tx0 + lane < a.W;     // partial last tile of a row when W % 64 != 0
-    const int p = p_ok ? p0 + lane : p0;
     const int ry0 = ty - RR, rx0 = tx0 - RR;
     float rly[TAPS], rlx[TAPS], rm[TAPS];
     int rbase[TAPS];
-    slim_recipe(a, b, p, p_ok, ty, tx0, lane, rly, rlx, rm, rbase);
+    if (!PREFETCH) slim_recipe_load(a, b, p, p_ok, raw);
+    slim_recipe_build(a, p_ok, ty, tx0, lane, raw, rly, rlx, rm, rbase);
+    if (PREFETCH && tile + 1 < t_end) {
+      int ty2, tx2, p2; bool ok2;
+      tile_geom(tile + 1, ty2, tx2, p2, ok2);
+      slim_recipe_load(a, b, p2, ok2, raw);
+    }
     bool any_fallback = false;
 #pragma unroll
     for (int t = 0; t < TAPS; ++t) any_fallback |= rbase[t] <= -3;
