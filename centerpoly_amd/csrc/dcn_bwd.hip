@@ -499,7 +499,11 @@ __global__ __launch_bounds__(256, WPS) void dcn_bwd_data_tiled_kernel(DcnBwdArgs
         const int rb = rbase[t];
         if (rb >= 0) {                     // out-of-image cells of the region hold 0
           const float v00 = xw[rb], v01 = xw[rb + 1], v10 = xw[rb + RWP], v11 = xw[rb + RWP + 1];
-          const float ly = rly[t], lx = rlx[t], hy = 1.f - ly, hx = 1.f - lx;
+          float ly = rly[t], lx = rlx[t];
+          // opaque to the optimiser: otherwise 1-ly, 1-lx and the four corner products of all
+          // nine taps are hoisted out of the channel loop and held in ~50 registers (spills)
+          asm volatile("" : "+v"(ly), "+v"(lx));
+          const float hy = 1.f - ly, hx = 1.f - lx;
           const float gc = gcT[lane * LDG + wid * TAPS + t];
           gm[t] += gc * (hy * hx * v00 + hy * lx * v01 + ly * hx * v10 + ly * lx * v11);
           const float gcm = gc * rm[t];
