@@ -342,7 +342,7 @@ __device__ __forceinline__ void fallback_decode(int rb, int W, int& fbase, unsig
 
 template <int CP, int WPS>                // Cout rounded up to 64/128/256; waves per SIMD
 __global__ __launch_bounds__(256, WPS) void dcn_bwd_data_tiled_kernel(DcnBwdArgs a) {
-  constexpr int LDO = CP + 1;
+  constexpr int LDO = CP + 2;             // stride 2 (mod 32): the lane = (row, k) fragment reads are conflict-free
   constexpr int WPT = (CP * KK + 255) / 256;
   constexpr int LDG = 49;
   constexpr int LDW = 49;                 // weight rows padded to 48 columns (+1): the three
@@ -597,7 +597,7 @@ __global__ __launch_bounds__(256, WPS) void dcn_bwd_data_tiled_kernel(DcnBwdArgs
 
 template <int CP, int WPS>
 void launch_tiled(const DcnBwdArgs& a, int tiles, hipStream_t st) {
-  const size_t lds = (size_t)(BM * (CP + 1) + CP * 49 + BM * 49 + KC * RSZ + 6 + 2 * KC * RSZ) * sizeof(float);
+  const size_t lds = (size_t)(BM * (CP + 2) + CP * 49 + BM * 49 + KC * RSZ + 6 + 2 * KC * RSZ) * sizeof(float);
   if (lds > 64 * 1024)
     (void)hipFuncSetAttribute((const void*)dcn_bwd_data_tiled_kernel<CP, WPS>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
