@@ -3,23 +3,31 @@
 
   N = 1 (default)  one step = one 2048x1024 image through DLA-34 + DCNv2 -> sigmoid -> fused
                    NMS/top-k/decode (BASELINE config 2); `value` = inference img/s.  The same
-                   line carries the 1-GPU training point (`train`), the DCNv2 forward roofline
-                   measured with HIP events inside the timed region (`roofline` against the
-                   fp32 matrix pipe that bounds it, `roofline_hbm` for the same launch against
-                   HBM) and the CPU oracle timed on a bounded sample
-                   (`cpu_baseline`).
+                   line carries the 1-GPU training point (`train`, with the DCNv2 backward
+                   rooflines), the DCNv2 forward roofline measured with HIP events inside the timed
+                   region (`roofline` against the fp32 matrix pipe that bounds it, `roofline_hbm`
+                   for the same launch against HBM), the same launch on other offset fields
+                   (`roofline_by_offsets`), BASELINE configs 4 and 5 (`other_configs`) and the CPU
+                   oracle timed on a bounded sample (`cpu_baseline`).
   N > 1            one step = one data-parallel training step (BASELINE config 3: DLA-34 + DCNv2,
                    4 images of 2048x1024 per GPU, 16-vertex cartesian head, l1+iou polygon loss,
                    Adam): forward, losses, backward with bucketed RCCL all-reduce, optimizer.
                    `value` = whole-job training img/s, weak scaling.
 
-Launch for N > 1:  python -m torch.distributed.run --nnodes=1 --nproc-per-node N
-                   --master-addr 127.0.0.1 --master-port P bench.py --gpus N --steps K --warmup W
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N ranks
+itself (a child `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr
+127.0.0.1 --master-port P bench.py --gpus N ...`, started BEFORE this process touches the GPU) and
+relays rank 0's JSON line; it refuses (exit code 2) when fewer than N devices are visible or when
+WORLD_SIZE disagrees with --gpus.  Under torch.distributed.run it is one rank of the job.
 """
 import argparse
 import contextlib
+import hashlib
 import json
 import os
+import socket
+import statistics
+import subprocess
 import sys
 import time
 
@@ -33,52 +41,93 @@ os.environ.setdefault("MIOPEN_CUSTOM_CACHE_DIR", _MIOPEN_CACHE)
 os.environ.setdefault("MIOPEN_USER_DB_PATH", os.path.join(_MIOPEN_CACHE, "db"))
 os.makedirs(os.environ["MIOPEN_USER_DB_PATH"], exist_ok=True)
 
-import numpy as np
-import torch
-import torch.distributed as dist
-
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 MFMA_F32_PEAK_TF = 157.3       # dense fp32 matrix peak
 HEADS = {"hm": 8, "poly": 32, "pseudo_depth": 1, "reg": 2}
+EXIT_REFUSED = 2
 
 
-def parse():
+def parse(argv=None):
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=20)
     p.add_argument("--warmup", type=int, default=5)
     p.add_argument("--mode", default="auto", choices=["auto", "infer", "train"])
+    p.add_argument("--config", default="auto", choices=["auto", "2", "3", "4", "5"],
+                   help="BASELINE config timed as `value`: auto = 2 at N=1, 3 at N>1; 4 = Hourglass-104 "
+                        "inference, 24-vertex polar; 5 = DLA-34 training at the KITTI shape, 8 img/GPU")
     p.add_argument("--height", type=int, default=1024)
     p.add_argument("--width", type=int, default=2048)
     p.add_argument("--train_batch", type=int, default=4, help="images per GPU in training")
-    p.add_argument("--train_steps", type=int, default=4, help="steps of the N=1 training point")
+    p.add_argument("--train_steps", type=int, default=8, help="steps of the N=1 training point")
     p.add_argument("--dcn_contraction", default="f32", choices=["f32", "bf16x3"],
                    help="DCNv2 forward contraction at inference: exact fp32 MFMA or split-bf16 x3")
     p.add_argument("--no_cpu_baseline", action="store_true")
     p.add_argument("--no_detector_point", action="store_true",
                    help="skip the end-to-end PolydetDetector.run point of the N=1 line")
     p.add_argument("--no_train_point", action="store_true")
-    return p.parse_args()
+    p.add_argument("--no_offset_points", action="store_true",
+                   help="skip the dominant DCNv2 launch on other offset fields")
+    p.add_argument("--no_other_configs", action="store_true",
+                   help="skip the BASELINE config 4 / 5 points of the N=1 line")
+    return p.parse_args(argv)
 
 
-def build_model(dev, train, dcn_contraction="f32"):
-    from centerpoly_amd import synth
-    from centerpoly_amd.models.model import create_model
-    model = create_model("dla_34", dict(HEADS), 256)
-    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
-    w = synth.fill_by_name(shapes)                      # random-init weights by name (no files)
-    for k in w:
-        if "conv_offset_mask" in k:
-            w[k] = (w[k] * 0.5).astype(w[k].dtype)
-    sd = {k: torch.from_numpy(v) for k, v in w.items()}
-    model.load_state_dict(sd)
-    model = model.to(dev)
-    model.train(train)
-    if not train and dev.type == "cuda":
-        model.prepare_inference(dcn_contraction=dcn_contraction)
-    return model, sd
+# ---------------------------------------------------------------- N-rank launch ---
+def launch_plan(args, environ, argv):
+    """What this process has to do, decided before anything touches the GPU:
+    ("run", None) -- be one rank (or the single process);  ("spawn", cmd) -- start the N ranks as
+    a child job and relay rank 0's line;  ("refuse", message) -- exit with EXIT_REFUSED."""
+    world_env = environ.get("WORLD_SIZE")
+    if args.gpus < 1:
+        return "refuse", "--gpus must be >= 1 (got %d)" % args.gpus
+    if world_env is not None:
+        if int(world_env) != args.gpus:
+            return "refuse", ("--gpus %d disagrees with WORLD_SIZE=%s: launch with --nproc-per-node %d"
+                              % (args.gpus, world_env, args.gpus))
+        return "run", None
+    if args.gpus == 1:
+        return "run", None
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    return "spawn", cmd
 
 
+def spawn_ranks(args, cmd):
+    import torch
+    have = torch.cuda.device_count()          # counting devices does not initialise the GPU
+    if have < args.gpus:
+        print("bench.py: --gpus %d but only %d HIP device(s) visible; refusing to report a %d-GPU line"
+              % (args.gpus, have, args.gpus), file=sys.stderr, flush=True)
+        return EXIT_REFUSED
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE)
+    line = None
+    for raw in proc.stdout.decode("utf-8", "replace").splitlines():
+        try:
+            cand = json.loads(raw)
+        except ValueError:
+            continue
+        if isinstance(cand, dict) and "metric" in cand:
+            line = cand
+    if proc.returncode != 0 or line is None:
+        print("bench.py: the %d-rank job failed (rc %d, JSON line %s)"
+              % (args.gpus, proc.returncode, "missing" if line is None else "present"), file=sys.stderr, flush=True)
+        return proc.returncode or 1
+    if line.get("n_gpus") != args.gpus:
+        print("bench.py: child reported n_gpus=%r, expected %d" % (line.get("n_gpus"), args.gpus),
+              file=sys.stderr, flush=True)
+        return 1
+    sys.stdout.write(json.dumps(line) + "\n")
+    sys.stdout.flush()
+    return 0
+
+
+# ------------------------------------------------------------------ helpers ---
 def note(msg):
     """Progress on stderr (the JSON line on stdout stays alone); MIOpen compiles kernels on
     first use, so the first step of each leg can take a minute on a fresh box."""
@@ -86,7 +135,32 @@ def note(msg):
         print("[bench %s] %s" % (time.strftime("%H:%M:%S"), msg), file=sys.stderr, flush=True)
 
 
+def build_model(dev, train, dcn_contraction="f32", arch="dla_34", heads=None, offset_weight_scale=0.5):
+    import torch
+    from centerpoly_amd import synth
+    from centerpoly_amd.models.model import create_model
+    heads = dict(heads or HEADS)
+    model = create_model(arch, heads, 256)
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    w = synth.fill_by_name(shapes)                      # random-init weights by name (no files)
+    for k in w:
+        if "conv_offset_mask" in k and offset_weight_scale != 1.0:
+            w[k] = (w[k] * offset_weight_scale).astype(w[k].dtype)
+    sd = {k: torch.from_numpy(v) for k, v in w.items()}
+    model.load_state_dict(sd)
+    model = model.to(dev)
+    model.train(train)
+    if not train and dev.type == "cuda" and hasattr(model, "prepare_inference"):
+        if arch.startswith("dla"):
+            model.prepare_inference(dcn_contraction=dcn_contraction)
+        else:
+            model.prepare_inference()
+    return model, sd
+
+
 def timed(fn, steps, warmup, world, tag=""):
+    import torch
+    import torch.distributed as dist
     for i in range(warmup):
         fn()
         torch.cuda.synchronize()
@@ -108,85 +182,172 @@ def timed(fn, steps, warmup, world, tag=""):
     return t
 
 
-def infer_leg(args, dev, world):
+def kernel_revision():
+    """Content hash of the DCNv2 forward kernel source: PMC traffic files are only trusted for the
+    kernel revision they were taken on."""
+    h = hashlib.sha256()
+    for f in ("dcn_fwd.hip", "cp_common.h"):
+        with open(os.path.join(ROOT, "centerpoly_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def measured_traffic(cin, cout, h, w, nb):
+    """HBM bytes per launch of the dominant DCNv2 forward launch from the committed rocprofv3 PMC
+    passes -- only when those passes were taken on bench.py's own tensors at the CURRENT kernel
+    revision (tools/pmc_bench_traffic.py writes the file); otherwise null."""
+    prof = os.path.join(ROOT, "profiles", "dcn_fwd_pmc.json")
+    try:
+        with open(prof) as fh:
+            d = json.load(fh)
+    except (OSError, ValueError):
+        return None, "no PMC file"
+    if d.get("kernel_rev") != kernel_revision():
+        return None, "PMC passes are from another kernel revision (%s): not reported" % d.get("kernel_rev")
+    if d.get("inputs") != "bench.py infer leg":
+        return None, "PMC passes were not taken on the bench inputs"
+    v = d.get("layers", {}).get("%dx%dx%dx%dx%d" % (nb, cin, cout, h, w))
+    if v is None:
+        return None, "launch shape not in the PMC file"
+    return float(v), "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this command (%s), gfx950 " \
+                     "FETCH_SIZE correction applied, kernel revision %s" % (d.get("command", "?"), d["kernel_rev"])
+
+
+def dcn_roofline(summary, tag="dcn_fwd"):
+    """Dominant launch of one DCNv2 kernel family: the layer shape with the largest total time in the
+    timed region.  Algorithmic bytes / FLOPs per launch: SURVEY.md 8(d); the backward kernels read
+    the forward's tensors plus grad_out and write the gradients of the same shapes."""
+    summary = {k: v for k, v in (summary or {}).items() if k[0] == tag}
+    if not summary:
+        return None, None
+    key = max(summary, key=lambda k: summary[k]["avg_ms"] * summary[k]["launches"])
+    _, cin, cout, h, w, nb = key
+    avg_s = summary[key]["avg_ms"] * 1e-3
+    fwd_bytes = 4.0 * (nb * (cin + 27 + cout) * h * w + 9 * cin * cout + cout)
+    gemm_flops = 2.0 * 9 * cin * cout * h * w * nb
+    traffic, traffic_src = (None, "not measured for this kernel")
+    if tag == "dcn_fwd":
+        alg_bytes, alg_flops, name = fwd_bytes, gemm_flops, "dcn_v2_forward"
+        traffic, traffic_src = measured_traffic(cin, cout, h, w, nb)
+    elif tag == "dcn_bwd_data":     # reads x, offset/mask, weight, grad_out; writes grad_x, grad_offset/mask
+        alg_bytes = 4.0 * (nb * (2 * cin + 2 * 27 + cout) * h * w + 9 * cin * cout)
+        alg_flops, name = gemm_flops, "dcn_v2_backward (data: grad_x, grad_offset, grad_mask)"
+    else:                           # reads x, offset/mask, grad_out; writes grad_weight
+        alg_bytes = 4.0 * (nb * (cin + 27 + cout) * h * w + 9 * cin * cout)
+        alg_flops, name = gemm_flops, "dcn_v2_backward (weight)"
+    layer = "%s %d->%d @%dx%d" % (name, cin, cout, h, w) + (" x%d images" % nb if nb != 1 else "")
+    common = {"traffic": traffic, "traffic_source": traffic_src, "kernel": layer, "avg_launch_us": avg_s * 1e6,
+              "launches": summary[key]["launches"]}
+    hbm = dict(common, bound="hbm", achieved=alg_bytes / avg_s / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
+               frac=alg_bytes / avg_s / 1e9 / HBM_PEAK_GBS, algorithmic_bytes_per_launch=alg_bytes)
+    mfma = dict(common, bound="mfma", achieved=alg_flops / avg_s / 1e12, peak=MFMA_F32_PEAK_TF, unit="TFLOP/s",
+                frac=alg_flops / avg_s / 1e12 / MFMA_F32_PEAK_TF, algorithmic_flops_per_launch=alg_flops)
+    return hbm, mfma
+
+
+# --------------------------------------------------------------------- legs ---
+def infer_leg(args, dev, world, arch="dla_34", heads=None, rep="cartesian", steps=None, warmup=None,
+              offset_weight_scale=0.5, tag="infer"):
+    import torch
     from centerpoly_amd import _C, synth
     from centerpoly_amd.models.decode import polydet_decode
-    model, _ = build_model(dev, train=False, dcn_contraction=args.dcn_contraction)
+    model, _ = build_model(dev, train=False, dcn_contraction=args.dcn_contraction, arch=arch, heads=heads,
+                           offset_weight_scale=offset_weight_scale)
     x = torch.from_numpy(synth.normal("bench/input", (1, 3, args.height, args.width))).to(dev)
 
     def step():
         with torch.no_grad():
             out = model(x)[-1]
             hm = out["hm"].sigmoid_()
-            return polydet_decode(hm, out["poly"], out["pseudo_depth"], reg=out["reg"], K=128,
-                                  rep="cartesian")
+            return polydet_decode(hm, out["poly"], out["pseudo_depth"], reg=out["reg"], K=128, rep=rep)
 
-    for i in range(args.warmup):
+    steps = args.steps if steps is None else steps
+    warmup = args.warmup if warmup is None else warmup
+    for i in range(warmup):
         step()
         torch.cuda.synchronize()
-        note("infer warmup %d/%d done" % (i + 1, args.warmup))
+        note("%s warmup %d/%d done" % (tag, i + 1, warmup))
     _C.kernel_timer = _C.KernelTimer()                 # HIP events around every DCN launch
-    t = timed(step, args.steps, 0, world, "infer")
-    note("infer timed region done")
+    t = timed(step, steps, 0, world, tag)
+    note("%s timed region done" % tag)
     summary = _C.kernel_timer.summary()
     _C.kernel_timer = None
+    del model
+    torch.cuda.empty_cache()
     return t, summary
 
 
-def dcn_roofline(summary):
-    """Dominant DCN launch: the layer shape with the largest total time in the timed region."""
-    if not summary:
-        return None, None
-    key = max(summary, key=lambda k: summary[k]["avg_ms"] * summary[k]["launches"])
-    _, cin, cout, h, w, nb = key
-    avg_s = summary[key]["avg_ms"] * 1e-3
-    alg_bytes = 4.0 * (nb * (cin + 27 + cout) * h * w + 9 * cin * cout + cout)   # SURVEY.md 8(d)
-    alg_flops = 2.0 * 9 * cin * cout * h * w * nb
-    traffic = None
-    prof = os.path.join(ROOT, "profiles", "dcn_fwd_pmc.json")
-    if os.path.exists(prof):
-        try:
-            traffic = json.load(open(prof)).get("%dx%dx%dx%d" % (cin, cout, h, w))
-        except Exception:
-            traffic = None
-    if nb != 1:
-        traffic = None                      # the PMC passes were taken on the single-image launch
-    layer = "dcn_v2_forward %d->%d @%dx%d" % (cin, cout, h, w) + (" x%d images" % nb if nb != 1 else "")
-    hbm = {"bound": "hbm", "achieved": alg_bytes / avg_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-           "frac": alg_bytes / avg_s / 1e9 / HBM_PEAK_GBS, "traffic": traffic, "kernel": layer,
-           "avg_launch_us": avg_s * 1e6, "launches": summary[key]["launches"],
-           "algorithmic_bytes_per_launch": alg_bytes}
-    mfma = {"bound": "mfma", "achieved": alg_flops / avg_s / 1e12, "peak": MFMA_F32_PEAK_TF,
-            "unit": "TFLOP/s", "frac": alg_flops / avg_s / 1e12 / MFMA_F32_PEAK_TF, "traffic": traffic,
-            "kernel": layer, "algorithmic_flops_per_launch": alg_flops,
-            "avg_launch_us": avg_s * 1e6, "launches": summary[key]["launches"]}
-    return hbm, mfma
-
-
-def train_leg(args, dev, world, rank, steps, warmup):
+def offset_field_points(dev, n=40):
+    """The dominant DCNv2 forward launch (64->64 @256x512, one image) on three synthetic offset
+    fields: white noise of 0.3 px and 1 px, and a smooth field of about 3 px (what a trained offset
+    branch produces).  The gathers' cost grows with the spatial noise of the offsets, so the
+    roofline fraction of the bench model (offset weights halved) is the optimistic end."""
+    import numpy as np
+    import torch
     from centerpoly_amd import synth
+    from centerpoly_amd.models.networks.DCNv2.dcn_v2 import dcn_v2_forward_raw
+    ci = co = 64
+    H, W = 256, 512
+    noise = synth.normal("bench/offsets/om", (1, 27, H, W))
+    small = noise.copy()
+    small[:, :18] *= 0.3
+    k = torch.full((1, 1, 9, 9), 1.0 / 81.0)
+    sm = torch.nn.functional.conv2d(torch.from_numpy(noise[:, :18]).reshape(18, 1, H, W), k, padding=4)
+    smooth = noise.copy()
+    smooth[:, :18] = (sm.reshape(1, 18, H, W) * 27.0).numpy()
+    x = torch.from_numpy(synth.normal("bench/offsets/x", (1, ci, H, W))).to(dev)
+    w = torch.from_numpy(synth.normal("bench/offsets/w", (co, ci, 3, 3), 0, 0.04)).to(dev)
+    b = torch.zeros(co, device=dev)
+    flops = 2.0 * 9 * ci * co * H * W
+    out = []
+    for name, om in (("white noise, std 0.3 px", small), ("white noise, std 1 px", noise),
+                     ("smooth field, std 3 px (9x9 box-filtered noise)", smooth)):
+        omt = torch.from_numpy(np.ascontiguousarray(om)).to(dev)
+        for _ in range(10):
+            dcn_v2_forward_raw(x, omt, w, b)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(n):
+            dcn_v2_forward_raw(x, omt, w, b)
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) / n * 1e3
+        out.append({"offsets": name, "avg_launch_us": us, "bound": "mfma", "achieved": flops / us / 1e6,
+                    "unit": "TFLOP/s", "peak": MFMA_F32_PEAK_TF, "frac": flops / us / 1e6 / MFMA_F32_PEAK_TF})
+    return {"kernel": "dcn_v2_forward 64->64 @256x512 (stand-alone launches, %d each)" % n, "points": out}
+
+
+def train_leg(args, dev, world, rank, steps, warmup, cfg="3"):
+    import torch
+    from centerpoly_amd import _C, synth
     from centerpoly_amd.opts import opts
     from centerpoly_amd.trains.train_factory import train_factory
+    if cfg == "5":
+        B, in_h, in_w, npts = 8, 384, 1280, 32
+        flags = ["--poly_loss", "l1", "--poly_order", "--nbr_points", "32", "--input_h", "384", "--input_w", "1280"]
+    else:
+        B, in_h, in_w, npts = args.train_batch, args.height, args.width, 16
+        flags = ["--poly_loss", "l1+iou", "--nbr_points", "16"]
     with contextlib.redirect_stdout(sys.stderr):          # stdout carries the JSON line only
-        opt = opts().init(["polydet", "--arch", "dla_34", "--poly_loss", "l1+iou", "--nbr_points", "16",
-                           "--batch_size", str(args.train_batch * world)])
+        opt = opts().init(["polydet", "--arch", "dla_34", "--batch_size", str(B * world)] + flags)
     opt.device = dev
-    model, _ = build_model(dev, train=True)
+    heads = dict(HEADS, poly=2 * npts)
+    model, _ = build_model(dev, train=True, heads=heads)
     optimizer = torch.optim.Adam(model.parameters(), opt.lr)
     trainer = train_factory["polydet"](opt, model, optimizer)
     trainer.set_device(opt.gpus, opt.chunk_sizes, dev)
-    B = args.train_batch
-    nb = synth.train_batch(B, args.height // 4, args.width // 4, nbr_points=16, rep="cartesian",
-                           stream="bench/train/rank%d" % rank, in_h=args.height, in_w=args.width)
+    nb = synth.train_batch(B, in_h // 4, in_w // 4, nbr_points=npts, rep="cartesian",
+                           stream="bench/train%s/rank%d" % (cfg, rank), in_h=in_h, in_w=in_w)
     batch = {k: torch.from_numpy(v).to(dev) for k, v in nb.items()}    # resident before timing
 
     def step():
         trainer.step(batch, train=True)
 
-    t = timed(step, steps, warmup, world, "train")
+    t = timed(step, steps, warmup, world, "train(cfg %s)" % cfg)
     note("train timed region done")
-    # the DCNv2 forward launches of two more (untimed) steps, HIP-event timed on rank 0
-    from centerpoly_amd import _C
+    # the DCNv2 launches of two more (untimed) steps, HIP-event timed on rank 0; with the timer on,
+    # the backward entry point is called once per gradient group (data / weight / bias)
     if rank == 0:
         _C.kernel_timer = _C.KernelTimer()
     for _ in range(2):
@@ -195,16 +356,33 @@ def train_leg(args, dev, world, rank, steps, warmup):
     _C.kernel_timer = None
     del trainer, model, optimizer, batch
     torch.cuda.empty_cache()
-    return t, summary
+    return t, summary, B, (in_h, in_w, npts)
+
+
+def train_rooflines(summary):
+    out = {}
+    for tag, name in (("dcn_fwd", "roofline"), ("dcn_bwd_data", "roofline_bwd_data"),
+                      ("dcn_bwd_weight", "roofline_bwd_weight")):
+        hbm, mfma = dcn_roofline(summary, tag)
+        if mfma is not None:
+            out[name] = mfma
+            out[name + "_hbm"] = hbm
+    if summary:
+        tot = {}
+        for k, v in summary.items():
+            tot[k[0]] = tot.get(k[0], 0.0) + v["avg_ms"] * v["launches"] / 2.0     # two traced steps
+        out["dcn_ms_per_step"] = {k: round(v, 3) for k, v in tot.items()}
+    return out
 
 
 def detector_leg(args, dev):
     """End-to-end PolydetDetector.run on a host uint8 image (upload over PCIe, device warp +
     normalise, network, decode, device affine post-process, copy back, per-class dicts)."""
+    import numpy as np
+    import torch
     from centerpoly_amd import synth
     from centerpoly_amd.detectors.detector_factory import detector_factory
     from centerpoly_amd.opts import opts
-    import numpy as np
     with contextlib.redirect_stdout(sys.stderr):
         opt = opts().init(["polydet", "--arch", "dla_34", "--input_h", str(args.height),
                            "--input_w", str(args.width)])
@@ -231,92 +409,180 @@ def detector_leg(args, dev):
                         % (args.width, args.height, (args.width | 31) + 1, (args.height | 31) + 1, opt.K)}
 
 
+def physical_cores():
+    """Physical cores this process may run on (the CPUs of its affinity mask, SMT siblings counted
+    once)."""
+    cpus = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else list(range(os.cpu_count() or 1))
+    cores = set()
+    for c in cpus:
+        try:
+            with open("/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list" % c) as fh:
+                cores.add(fh.read().strip())
+        except OSError:
+            cores.add(str(c))
+    return max(1, len(cores)), len(cpus)
+
+
 def cpu_baseline(args):
-    """The CPU oracle (a port of the reference's path) on a bounded sample: ONE full-size
-    image through DLA-34 + DCNv2 + decode (a few seconds on a 16-core host share)."""
+    """The CPU oracle (a port of the reference's path) on a bounded sample: full-size images through
+    DLA-34 + DCNv2 + sigmoid + decode, 1 warm-up + 3 timed passes, median, one thread per physical
+    core this process may use (SURVEY 8(d) protocol, pass count bounded to about 30 s)."""
+    import torch
     from centerpoly_amd import synth
     from oracle import decode as odec
     from oracle import nets as onet
-    # a one-GPU box owns a 16-core share of the host: more threads only oversubscribe it
-    threads = min(os.cpu_count() or 1, 16)
-    torch.set_num_threads(threads)
-    note("cpu baseline (oracle on %d threads) ..." % threads)
+    cores, logical = physical_cores()
+    torch.set_num_threads(cores)
+    note("cpu baseline (oracle on %d threads = physical cores; %d logical CPUs in the affinity mask) ..."
+         % (cores, logical))
     h, w = args.height, args.width
     _, sd = build_model(torch.device("cpu"), train=False)
     x = torch.from_numpy(synth.normal("bench/cpu/input", (1, 3, h, w)))
-    t0 = time.perf_counter()
-    with torch.no_grad():
-        out = onet.dla_seg_forward(sd, x, dict(HEADS))[0]
-        odec.polydet_decode(torch.sigmoid(out["hm"]), out["poly"], out["pseudo_depth"], out["reg"], K=128)
-    t = time.perf_counter() - t0
-    return {"value": 1.0 / t, "unit": "img/s", "cores": threads, "kind": "port",
-            "sample": "1 image at %dx%d through the oracle's DLA-34+DCNv2 forward + sigmoid + "
-                      "decode, %.1f s wall" % (w, h, t)}
+
+    def one():
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            out = onet.dla_seg_forward(sd, x, dict(HEADS))[0]
+            odec.polydet_decode(torch.sigmoid(out["hm"]), out["poly"], out["pseudo_depth"], out["reg"], K=128)
+        return time.perf_counter() - t0
+
+    warm = one()
+    ts = [one() for _ in range(3)]
+    t = statistics.median(ts)
+    return {"value": 1.0 / t, "unit": "img/s", "cores": cores, "kind": "port",
+            "sample": "%dx%d images through the oracle's DLA-34+DCNv2 forward + sigmoid + decode: 1 warm-up "
+                      "(%.1f s) + 3 timed passes (%s s), median; %d threads = physical cores of this "
+                      "process's CPU share (%d logical)" % (w, h, warm, "/".join("%.1f" % v for v in ts),
+                                                            cores, logical)}
 
 
-def main():
-    args = parse()
+def other_config_points(args, dev):
+    """BASELINE configs 4 and 5 on one GPU (their per-GPU share), so that they are driver-run numbers."""
+    out = {}
+    try:
+        heads = {"hm": 8, "poly": 48, "pseudo_depth": 1, "reg": 2}
+        t, _ = infer_leg(args, dev, 1, arch="hourglass", heads=heads, rep="polar", steps=8, warmup=2,
+                         offset_weight_scale=1.0, tag="config4")
+        out["config4"] = {"workload": "BASELINE config 4: Hourglass-104 (2 stacks), 1x3x%dx%d, 24-vertex polar "
+                                      "head, K=128, forward + sigmoid + decode" % (args.height, args.width),
+                          "metric": "inference img/s", "value": 8 / t, "ms_per_step": 1e3 * t / 8, "steps": 8,
+                          "warmup": 2, "n_gpus": 1}
+    except Exception as e:                                   # never lose the main line to a side point
+        out["config4"] = {"error": "%s: %s" % (type(e).__name__, e)}
+    try:
+        t, summary, B, _ = train_leg(args, dev, 1, 0, 6, 2, cfg="5")
+        out["config5"] = dict({"workload": "BASELINE config 5 per-GPU share: DLA-34 + DCNv2 training, 8 x 3x384x1280, "
+                                           "32-vertex cartesian, l1 + order loss, Adam",
+                               "metric": "train img/s", "value": B * 6 / t, "ms_per_step": 1e3 * t / 6, "steps": 6,
+                               "warmup": 2, "n_gpus": 1}, **train_rooflines(summary))
+    except Exception as e:
+        out["config5"] = {"error": "%s: %s" % (type(e).__name__, e)}
+    return out
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse(argv)
+    plan, detail = launch_plan(args, os.environ, argv)
+    if plan == "refuse":
+        print("bench.py: " + detail, file=sys.stderr, flush=True)
+        return EXIT_REFUSED
+    if plan == "spawn":
+        return spawn_ranks(args, detail)
+
+    import torch
+    import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a HIP device (there is no CPU fallback)")
+        print("bench.py needs a HIP device (there is no CPU fallback)", file=sys.stderr, flush=True)
+        return EXIT_REFUSED
+    if torch.cuda.device_count() <= local_rank:
+        print("bench.py: rank %d has no device %d" % (rank, local_rank), file=sys.stderr, flush=True)
+        return EXIT_REFUSED
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=dev)
-    mode = args.mode if args.mode != "auto" else ("infer" if world == 1 else "train")
+    cfg = args.config
+    if cfg == "auto":
+        if args.mode == "auto":
+            cfg = "2" if world == 1 else "3"
+        else:
+            cfg = "2" if args.mode == "infer" else "3"
+    mode = "infer" if cfg in ("2", "4") else "train"
     torch.backends.cudnn.benchmark = os.environ.get("CP_MIOPEN_BENCHMARK", "0") == "1"
     line = {"n_gpus": world, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic (counter-hash inputs, name-hashed random-init weights)"}
     if mode == "infer":
-        t, summary = infer_leg(args, dev, world)
+        if cfg == "4":
+            heads = {"hm": 8, "poly": 48, "pseudo_depth": 1, "reg": 2}
+            t, summary = infer_leg(args, dev, world, arch="hourglass", heads=heads, rep="polar",
+                                   offset_weight_scale=1.0)
+            workload = ("BASELINE config 4: Hourglass-104 (2 stacks), 1x3x%dx%d synthetic, 24-vertex polar head, "
+                        "K=128, forward + sigmoid + NMS/top-k/decode" % (args.height, args.width))
+            metric = "inference img/s @2048x1024 Hourglass-104 (1 GPU)"
+        else:
+            t, summary = infer_leg(args, dev, world)
+            workload = ("BASELINE config 2: DLA-34 + DCNv2, 1x3x%dx%d synthetic, 16-vertex cartesian head, "
+                        "K=128, forward + sigmoid + NMS/top-k/decode" % (args.height, args.width))
+            metric = "inference img/s @2048x1024 DLA-34 (1 GPU)"
         hbm, mfma = dcn_roofline(summary)
         line.update({
-            "metric": "inference img/s @2048x1024 DLA-34 (1 GPU)", "unit": "img/s",
+            "metric": metric, "unit": "img/s",
             "value": world * args.steps / t, "ms_per_step": 1e3 * t / args.steps,
-            "config": {"workload": "BASELINE config 2: DLA-34 + DCNv2, 1x3x%dx%d synthetic, 16-vertex "
-                                   "cartesian head, K=128, forward + sigmoid + NMS/top-k/decode"
-                                   % (args.height, args.width),
-                       "images_per_step": world, "parallelism": "replicas" if world > 1 else "single"},
+            "config": {"workload": workload, "images_per_step": world,
+                       "parallelism": "replicas" if world > 1 else "single"},
             # the dominant kernel's arithmetic intensity (119 FLOP/B) is 6x the fp32 ridge point
             # (157.3 TFLOP/s / 8 TB/s = 19.7 FLOP/B): the fp32 matrix pipe is the binding roofline,
             # the HBM fraction of the same launch is reported beside it
             "roofline": mfma, "roofline_hbm": hbm,
             "dcn_layers_ms": {"%d->%d@%dx%d" % k[1:5]: round(v["avg_ms"], 4) for k, v in summary.items()},
         })
-        if world == 1 and not args.no_detector_point:
-            line["detector_end_to_end"] = detector_leg(args, dev)
-            note("detector end-to-end point done")
-        if world == 1 and not args.no_train_point:
-            tt, _ = train_leg(args, dev, 1, 0, args.train_steps, 2)
-            # same workload per GPU as the N > 1 lines: the 1-GPU point of the training scaling curve
-            line["train"] = {"metric": "train img/s 1/2/4/8 GPU @2048x1024 DLA-34",
-                             "value": args.train_batch * args.train_steps / tt,
-                             "ms_per_step": 1e3 * tt / args.train_steps, "n_gpus": 1,
-                             "global_batch": args.train_batch, "steps": args.train_steps,
-                             "workload": "BASELINE config 3 per-GPU share: DLA-34 + DCNv2, %d x 3x%dx%d, "
-                                         "l1+iou polygon loss, Adam" % (args.train_batch, args.height, args.width)}
+        if world == 1 and cfg == "2":
+            if not args.no_offset_points:
+                line["roofline_by_offsets"] = offset_field_points(dev)
+                t1, s1 = infer_leg(args, dev, 1, steps=10, warmup=2, offset_weight_scale=1.0, tag="infer(unscaled)")
+                _, m1 = dcn_roofline(s1)
+                line["infer_unscaled_offset_weights"] = {
+                    "what": "the same step with conv_offset_mask weights at their full fan-in scale (offsets "
+                            "twice as large as in `value`'s model)",
+                    "value": 10 / t1, "ms_per_step": 1e3 * t1 / 10, "steps": 10, "roofline": m1}
+                note("offset-field points done")
+            if not args.no_detector_point:
+                line["detector_end_to_end"] = detector_leg(args, dev)
+                note("detector end-to-end point done")
+            if not args.no_train_point:
+                tt, ts, B, _ = train_leg(args, dev, 1, 0, args.train_steps, 2)
+                # same workload per GPU as the N > 1 lines: the 1-GPU point of the training scaling curve
+                line["train"] = dict({"metric": "train img/s 1/2/4/8 GPU @2048x1024 DLA-34",
+                                      "value": B * args.train_steps / tt,
+                                      "ms_per_step": 1e3 * tt / args.train_steps, "n_gpus": 1,
+                                      "global_batch": B, "steps": args.train_steps, "warmup": 2,
+                                      "workload": "BASELINE config 3 per-GPU share: DLA-34 + DCNv2, %d x 3x%dx%d, "
+                                                  "l1+iou polygon loss, Adam" % (B, args.height, args.width)},
+                                     **train_rooflines(ts))
+            if not args.no_other_configs:
+                line["other_configs"] = other_config_points(args, dev)
     else:
-        t, summary = train_leg(args, dev, world, rank, args.steps, args.warmup)
-        hbm, mfma = dcn_roofline(summary) if rank == 0 else (None, None)
+        t, summary, B, (in_h, in_w, npts) = train_leg(args, dev, world, rank, args.steps, args.warmup, cfg=cfg)
         line.update({
-            "metric": "train img/s 1/2/4/8 GPU @2048x1024 DLA-34", "unit": "img/s",
-            "value": world * args.train_batch * args.steps / t, "ms_per_step": 1e3 * t / args.steps,
-            "config": {"workload": "BASELINE config 3: DLA-34 + DCNv2 training, %d x 3x%dx%d per GPU, "
-                                   "16-vertex cartesian + l1+iou polygon loss, Adam lr 4e-6"
-                                   % (args.train_batch, args.height, args.width),
-                       "global_batch": world * args.train_batch,
+            "metric": "train img/s 1/2/4/8 GPU @%dx%d DLA-34" % (in_w, in_h), "unit": "img/s",
+            "value": world * B * args.steps / t, "ms_per_step": 1e3 * t / args.steps,
+            "config": {"workload": "BASELINE config %s: DLA-34 + DCNv2 training, %d x 3x%dx%d per GPU, "
+                                   "%d-vertex cartesian, %s, Adam lr 4e-6"
+                                   % (cfg, B, in_h, in_w, npts,
+                                      "l1+iou polygon loss" if cfg == "3" else "l1 + order loss"),
+                       "global_batch": world * B,
                        "parallelism": "dp%d (one process per GPU, RCCL all-reduce)" % world},
-            # dominant DCNv2 FORWARD launch of the training step (fp32 matrix pipe is its bound);
-            # the backward kernels are priced in DESIGN.md 4.2
-            "roofline": mfma, "roofline_hbm": hbm,
             "scaling_base": "weak scaling of the training leg: compare with the N=1 line's "
-                            "train.value (same %d img/GPU workload), not with its inference value"
-                            % args.train_batch,
+                            "train.value (same %d img/GPU workload), not with its inference value" % B,
         })
+        if rank == 0:
+            line.update(train_rooflines(summary))      # forward (`roofline`) and both backward kernels
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args)
@@ -324,7 +590,8 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

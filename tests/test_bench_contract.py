@@ -35,3 +35,63 @@ def test_product_never_imports_oracle():
     for f in ("main.py", "test.py"):
         text = open(os.path.join(ROOT, f)).read()
         assert "oracle" not in text, f
+
+
+def _bench():
+    import importlib
+    import sys
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    return importlib.import_module("bench")
+
+
+def test_launch_plan_spawns_n_ranks_or_refuses():
+    """`--gpus N` must never silently become a 1-GPU line (round-1 defect): without WORLD_SIZE it
+    plans an N-rank torch.distributed.run child, with a disagreeing WORLD_SIZE it refuses."""
+    bench = _bench()
+    argv = ["--gpus", "4", "--steps", "3", "--warmup", "1"]
+    args = bench.parse(argv)
+    plan, cmd = bench.launch_plan(args, {}, argv)
+    assert plan == "spawn"
+    assert cmd[1:3] == ["-m", "torch.distributed.run"]
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "4"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-len(argv):] == argv and cmd[-len(argv) - 1].endswith("bench.py")
+    assert bench.launch_plan(args, {"WORLD_SIZE": "4"}, argv) == ("run", None)
+    assert bench.launch_plan(args, {"WORLD_SIZE": "2"}, argv)[0] == "refuse"
+    one = bench.parse([])
+    assert bench.launch_plan(one, {}, []) == ("run", None)
+    assert bench.launch_plan(one, {"WORLD_SIZE": "8"}, [])[0] == "refuse"
+
+
+def test_gpus_2_without_enough_devices_exits_nonzero_and_prints_no_line():
+    """On a box with fewer than N devices (this container: 0, a gpurun box: 1) `--gpus 2` exits with
+    the refusal code and prints no JSON line -- it does not fall into the 1-GPU inference leg."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    import torch
+    if torch.cuda.device_count() >= 2:
+        import pytest
+        pytest.skip("two devices present: the spawn path would run the real job")
+    assert p.returncode == 2, p.stderr.decode()[-400:]
+    assert p.stdout.strip() == b""
+    assert b"refusing" in p.stderr
+
+
+def test_traffic_is_null_for_a_stale_kernel_revision(tmp_path, monkeypatch):
+    bench = _bench()
+    import json
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    monkeypatch.setattr(bench, "kernel_revision", lambda: "abc")
+    (prof / "dcn_fwd_pmc.json").write_text(json.dumps(
+        {"kernel_rev": "old", "inputs": "bench.py infer leg", "layers": {"1x64x64x256x512": 1.0}}))
+    assert bench.measured_traffic(64, 64, 256, 512, 1)[0] is None
+    (prof / "dcn_fwd_pmc.json").write_text(json.dumps(
+        {"kernel_rev": "abc", "inputs": "bench.py infer leg", "layers": {"1x64x64x256x512": 5.0}}))
+    assert bench.measured_traffic(64, 64, 256, 512, 1)[0] == 5.0
+    assert bench.measured_traffic(64, 64, 256, 512, 4)[0] is None

@@ -1,0 +1,44 @@
+"""Reduce two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) taken over `bench.py --config 2` (the
+inference leg on the bench's own tensors) to HBM bytes per launch of the DCNv2 forward launches, keyed
+by launch shape, stamped with the kernel revision bench.py checks.
+
+  python3 tools/pmc_bench_traffic.py <fetch_dir> <write_dir> <out.json>
+
+Correction (MI355X_MICROARCH.md, HBM): gfx950's FETCH_SIZE reports half of the bytes of a wide
+coalesced stream, WRITE_SIZE is exact; traffic = (2*FETCH_SIZE + WRITE_SIZE) KB.  This kernel's reads
+are 8-byte gathers, for which the doubling is an upper bound (stated in the JSON)."""
+import csv, glob, json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+
+# (B, Cin, Cout, H, W) of the DLA-34 DCN layers at 2048x1024 by launch grid (threads): 256 threads per
+# 64-pixel tile; layers with Cout > 128 or under-filled grids use other grids and are not keyed here
+SHAPES = {524288: (1, 64, 64, 256, 512)}
+
+
+def avg(dirname, counter):
+    vals = {}
+    for f in glob.glob(os.path.join(dirname, "**", "*counter_collection.csv"), recursive=True):
+        for row in csv.DictReader(open(f)):
+            if "dcn_fwd" in row["Kernel_Name"] and row["Counter_Name"] == counter:
+                vals.setdefault(int(row["Grid_Size"]), []).append(float(row["Counter_Value"]))
+    return {g: (sum(v) / len(v), len(v)) for g, v in vals.items()}
+
+
+fetch, write = avg(sys.argv[1], "FETCH_SIZE"), avg(sys.argv[2], "WRITE_SIZE")
+layers, raw = {}, {}
+for grid, shape in SHAPES.items():
+    if grid in fetch and grid in write:
+        f, n = fetch[grid]
+        w, _ = write[grid]
+        layers["%dx%dx%dx%dx%d" % shape] = (2.0 * f + w) * 1024.0
+        raw["%dx%dx%dx%dx%d" % shape] = {"FETCH_SIZE_KB_avg": f, "WRITE_SIZE_KB_avg": w, "launches": n}
+out = {"kernel_rev": bench.kernel_revision(), "inputs": "bench.py infer leg",
+       "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE --output-format csv -- python3 bench.py "
+                  "--config 2 --steps 3 --warmup 2 --no_cpu_baseline --no_train_point --no_detector_point "
+                  "--no_offset_points --no_other_configs (separate passes)",
+       "correction": "traffic = (2*FETCH_SIZE + WRITE_SIZE)*1024 bytes; the doubling is calibrated for wide coalesced "
+                     "streams, this kernel reads 8-byte gathers, so the read side is an upper bound",
+       "layers": layers, "_raw": raw}
+json.dump(out, open(sys.argv[3], "w"), indent=1)
+print(json.dumps(out))
