@@ -410,8 +410,9 @@ def detector_leg(args, dev):
 
 
 def physical_cores():
-    """Physical cores this process may run on (the CPUs of its affinity mask, SMT siblings counted
-    once)."""
+    """CPU share of this process: physical cores of its affinity mask (SMT siblings counted once), capped by
+    the cgroup CPU quota when one is set (a one-GPU box owns a 16-core share of a much larger host; more
+    threads than the quota only thrash).  Returns (threads to use, logical CPUs in the mask, quota or None)."""
     cpus = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else list(range(os.cpu_count() or 1))
     cores = set()
     for c in cpus:
@@ -420,7 +421,25 @@ def physical_cores():
                 cores.add(fh.read().strip())
         except OSError:
             cores.add(str(c))
-    return max(1, len(cores)), len(cpus)
+    quota = None
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as fh:
+                parts = fh.read().split()
+            if path.endswith("cpu.max"):
+                if parts[0] != "max":
+                    quota = float(parts[0]) / float(parts[1])
+            elif float(parts[0]) > 0:
+                with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as fh:
+                    quota = float(parts[0]) / float(fh.read().split()[0])
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    n = max(1, len(cores))
+    if quota is not None:
+        n = max(1, min(n, int(quota + 0.5)))
+    n = min(n, int(os.environ.get("CP_CPU_BASELINE_THREADS", "32")))     # bound: the oracle stops scaling past ~32 threads
+    return n, len(cpus), quota
 
 
 def cpu_baseline(args):
@@ -431,10 +450,10 @@ def cpu_baseline(args):
     from centerpoly_amd import synth
     from oracle import decode as odec
     from oracle import nets as onet
-    cores, logical = physical_cores()
+    cores, logical, quota = physical_cores()
     torch.set_num_threads(cores)
-    note("cpu baseline (oracle on %d threads = physical cores; %d logical CPUs in the affinity mask) ..."
-         % (cores, logical))
+    note("cpu baseline (oracle on %d threads; %d logical CPUs in the affinity mask, cgroup quota %s) ..."
+         % (cores, logical, quota))
     h, w = args.height, args.width
     _, sd = build_model(torch.device("cpu"), train=False)
     x = torch.from_numpy(synth.normal("bench/cpu/input", (1, 3, h, w)))
@@ -451,9 +470,9 @@ def cpu_baseline(args):
     t = statistics.median(ts)
     return {"value": 1.0 / t, "unit": "img/s", "cores": cores, "kind": "port",
             "sample": "%dx%d images through the oracle's DLA-34+DCNv2 forward + sigmoid + decode: 1 warm-up "
-                      "(%.1f s) + 3 timed passes (%s s), median; %d threads = physical cores of this "
-                      "process's CPU share (%d logical)" % (w, h, warm, "/".join("%.1f" % v for v in ts),
-                                                            cores, logical)}
+                      "(%.1f s) + 3 timed passes (%s s), median; %d threads (physical cores of this process's "
+                      "CPU share: %d logical CPUs in the affinity mask, cgroup quota %s, capped at 32)"
+                      % (w, h, warm, "/".join("%.1f" % v for v in ts), cores, logical, quota)}
 
 
 def other_config_points(args, dev):

@@ -10,7 +10,7 @@ import sys
 
 __version__ = "0.1.0"
 
-_MIRRORED = ("models", "trains", "detectors", "utils", "external", "opts")
+_MIRRORED = ("models", "trains", "detectors", "utils", "external", "opts", "logger", "datasets")
 
 
 def install_as_reference_lib():
@@ -24,5 +24,6 @@ def install_as_reference_lib():
                 "models.networks.pose_dla_dcn", "models.networks.large_hourglass",
                 "models.networks.DCNv2.dcn_v2", "trains.train_factory", "trains.polydet",
                 "trains.base_trainer", "detectors.detector_factory", "detectors.polydet",
-                "detectors.base_detector", "utils.image", "utils.post_process", "external.nms"):
+                "detectors.base_detector", "utils.image", "utils.post_process", "utils.utils", "external.nms",
+                "models.data_parallel", "datasets.dataset_factory", "datasets.sample.polydet"):
         sys.modules.setdefault(sub, importlib.import_module("centerpoly_amd." + sub))

@@ -966,7 +966,26 @@ inline int out_extent(int in, int pad, int dil, int stride) {
 
 }  // namespace
 
-extern "C" size_t cp_dcn_v2_backward_workspace_bytes(const cp_dcn_shape*) { return 0; }
+// dcn_bwd_data.hip: the register-resident grad-column kernel for the data gradients
+bool cp_dcn_bwd_data2_supported(const cp_dcn_shape* s);
+size_t cp_dcn_bwd_data2_workspace_bytes(const cp_dcn_shape* s);
+int cp_dcn_bwd_data2(const cp_dcn_shape* s, const float* x, const float* offset, int64_t offset_bstride,
+                     const float* mask, int64_t mask_bstride, int32_t mask_is_logit, const float* weight,
+                     const float* grad_out, float* grad_x, float* grad_offset, int64_t grad_offset_bstride,
+                     float* grad_mask, int64_t grad_mask_bstride, void* workspace, size_t workspace_bytes,
+                     hipStream_t st);
+
+// A/B switch for timing runs (tools/probe_dcn_bwd.py): CP_DCN_BWD_V1=1 keeps the round-1 data kernel.
+// Read once per process, never on the call path.
+static bool use_v1_data_kernel() {
+  static const bool v1 = [] { const char* e = getenv("CP_DCN_BWD_V1"); return e && e[0] == '1'; }();
+  return v1;
+}
+
+extern "C" size_t cp_dcn_v2_backward_workspace_bytes(const cp_dcn_shape* s) {
+  if (!s || s->kh != 3 || s->kw != 3 || s->deformable_groups != 1) return 0;
+  return cp_dcn_bwd_data2_workspace_bytes(s);
+}
 
 extern "C" int cp_dcn_v2_backward(const cp_dcn_shape* s, const float* x, const float* offset,
                                   int64_t offset_bstride, const float* mask,
@@ -974,8 +993,8 @@ extern "C" int cp_dcn_v2_backward(const cp_dcn_shape* s, const float* x, const f
                                   const float* weight, const float* grad_out, float* grad_x,
                                   float* grad_offset, int64_t grad_offset_bstride,
                                   float* grad_mask, int64_t grad_mask_bstride, float* grad_weight,
-                                  float* grad_bias, void* /*workspace*/,
-                                  size_t /*workspace_bytes*/, void* stream) {
+                                  float* grad_bias, void* workspace,
+                                  size_t workspace_bytes, void* stream) {
   CP_CHECK_ARG(s && x && offset && mask && weight && grad_out);
   CP_CHECK_ARG(s->B > 0 && s->Cin > 0 && s->H > 0 && s->W > 0 && s->Cout > 0);
   CP_CHECK_ARG(s->stride > 0 && s->dil > 0 && s->pad >= 0);
@@ -1005,7 +1024,16 @@ extern "C" int cp_dcn_v2_backward(const cp_dcn_shape* s, const float* x, const f
   const bool same_size = s->stride == 1 && Wo == s->W && Ho == s->H &&
                          (unsigned long long)s->Cout * Ho * Wo * 4ull < 0xE0000000ull &&
                          (long long)s->H * s->W < (1ll << 27);     // fallback index packed with 4 bits
-  if (grad_x || grad_offset || grad_mask) {
+  bool data_done = false;
+  if ((grad_x || grad_offset || grad_mask) && cp_dcn_bwd_data2_supported(s) && !use_v1_data_kernel() &&
+      workspace && workspace_bytes >= cp_dcn_bwd_data2_workspace_bytes(s)) {
+    const int rc = cp_dcn_bwd_data2(s, x, offset, offset_bstride, mask, mask_bstride, mask_is_logit, weight, grad_out,
+                                    grad_x, grad_offset, grad_offset_bstride, grad_mask, grad_mask_bstride, workspace,
+                                    workspace_bytes, st);
+    if (rc != CP_OK) return rc;
+    data_done = true;
+  }
+  if (!data_done && (grad_x || grad_offset || grad_mask)) {
     const bool tiled = s->Cout <= 256 && same_size;
     if (tiled) {
       if (s->Cout <= 64) launch_tiled<64, 2>(a, row_tiles, st);

@@ -1,0 +1,752 @@
+// DCNv2 backward, data gradients (grad_x, grad_offset, grad_mask) for gfx950 -- register-resident
+// grad-column kernel.
+//
+// Replaces upstream's dcn_v2_backward data path (columns in HBM + cuBLAS + atomic col2im) behind
+// `from .DCNv2.dcn_v2 import DCN` (reference: src/lib/models/networks/pose_dla_dcn.py:16,354).
+//
+// One workgroup = a TILE of TH rows x 16 pixels of one image (one wave per row) x a slice of the
+// input channels, walked in chunks of 16 channels.  Per chunk and wave:
+//
+//   gcol^T[c][px] (tap t) = sum_co W[co][c][t] * go[co][px]         v_mfma_f32_16x16x4_f32
+//
+// is computed TRANSPOSED: the weights are the A operand (rows = the chunk's 16 channels), the
+// wave's 16 grad_out pixels the B operand (held in registers for the whole kernel), one
+// accumulator per tap.  The result lands with the PIXEL on the lane (lane & 15) and four
+// CHANNELS in the accumulator registers (4 * (lane >> 4) + reg): exactly the layout the
+// consumption needs, so the grad columns never touch LDS or HBM, all 9 x 16 columns of the
+// m-tiles are useful (the previous kernel padded 36 columns to 48) and the matrix operands cost
+// 36 ds_read_b128 per 144 MFMAs (weights pre-permuted into fragment order by a prologue kernel).
+//
+// Consumption per (pixel, tap, channel): 4 corner reads from an LDS-staged input region
+// ((TH+6) x 22 cells per channel, coalesced row loads), the bilinear algebra for grad_mask /
+// grad_offset (register sums over the lane's channels, shuffled together once per tile), and 4
+// grad_x contributions accumulated in a matching LDS region in 64-bit fixed point.
+//   * fixed point: contribution -> fma((double)gcol*m, (double)w*scale, 2^52+2^51); the raw bits of
+//     that double are added with ds_add_u64 (LDS float atomics run 25x slower on gfx950,
+//     tools/micro/lds_atomic_rate.hip).  Every add carries the constant 0x4338<<48 in its top 16
+//     bits and the rounded integer in two's complement below, so the low 48 bits of the cell are the
+//     exact integer sum whatever the number and order of adds; `scale` = 2^35 / (a bound of |gcol|
+//     from the tile's max L1 norm of grad_out and max|W|) leaves 2^12 adds of headroom (a cell gets
+//     at most TH*16*9 = 1152).  Order-independent, i.e. run-to-run deterministic.
+//   * flush: after each chunk the region sums are written with PLAIN coalesced stores to the
+//     tile's slab in the caller's workspace; a second kernel adds, for every grad_x element, the
+//     (at most four) slabs whose region covers it, in a fixed order.  No global float atomics on
+//     the hot path: the round-1 kernel issued 2.0e7 64-B atomic requests (1.3 GB) per launch at
+//     64->64 @256x512 x4 and ran at the chip's atomic rate (profiles/r02_dcn_bwd_pmc_baseline_*).
+// Taps whose corners leave the region (|offset| > 2 px) take a cold path with global gathers and
+// float atomics straight into grad_x (which is why grad_x stays "accumulated into").
+//
+// Small-spatial layers split the input channels over workgroups (grid z); their partial
+// grad_offset / grad_mask sums meet in a reduce kernel.
+#include "cp_common.h"
+
+#include <stdlib.h>
+#include <type_traits>
+
+namespace {
+
+// compile-time loop: f(std::integral_constant<int, I>) for I in [I0, N)
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+
+constexpr int TAPS = 9;
+constexpr int TW = 16;                     // tile width: one MFMA n-tile of pixels per wave
+constexpr int KC = 16;                     // channels per chunk: one MFMA m-tile
+constexpr int HALO = 3;                    // region halo in pixels (offsets within +-2 px stay in LDS)
+constexpr int A_F4 = TAPS * 4 * 64;        // float4 elements of one weight stage (64 co x 16 c x 9 taps)
+constexpr unsigned OOB = 0x80000000u;      // buffer offset past every tensor (reads 0)
+constexpr double FX_MAGIC = 6755399441055744.0;   // 2^52 + 2^51
+
+constexpr int HALO_L = 4;                  // columns left of the tile: the tile's own 16 columns start 16-B aligned
+constexpr int RWD = 24;                    // region row: 4 + 16 + 4 columns (x offsets within about +-3 px)
+
+template <int TH>
+struct Geo {
+  static constexpr int RH = TH + 2 * HALO, RSZ = RH * RWD;
+  // channel stride of the LDS regions: = 4 (mod 8), so the four channel groups of a lane quad
+  // (4 * RSZP apart) start 16 banks apart
+  static constexpr int RSZP = RSZ + ((4 - RSZ % 8) + 8) % 8;
+  static constexpr int NPX = TH * TW, NTHR = TH * 64;
+};
+
+struct D2Args {
+  const float* x;
+  const float* offset;
+  const float* mask;
+  const float* go;
+  const f32x4* wp;           // permuted weights [chunk][slab][tap][ks4][lane] x 4 floats
+  const float* wmax;         // max |W|
+  float* gx;                 // cold path only (may be null)
+  float* slab;               // [B][tiles][Cin][RSZ]
+  float* goff;               // slices == 1: final tensors; else partial sums [slice][B][27][HW]
+  float* gmask;
+  long long offset_bstride, mask_bstride, goff_bstride, gmask_bstride, part_sstride;
+  int B, Cin, H, W, Cout;
+  int pad, dil, mask_is_logit;
+  int tpr, ntiles;           // tiles per row, tiles per image
+  int chunks, chunks_per_slice;
+#ifdef CP_STAMP
+  unsigned long long* dbg;   // diagnostic build only: per-wave cycle sums [block][wave][8]
+#endif
+};
+
+#ifdef CP_STAMP
+#define CP_T() __builtin_amdgcn_s_memtime()
+#define CP_ACC(var, t0) var += (CP_T() - (t0))
+#else
+#define CP_T() 0ull
+#define CP_ACC(var, t0) (void)0
+#endif
+
+// ---- prologue: weights into MFMA-fragment order + max |W| -------------------------------------
+// wp[((chunk*NS + slab)*9 + t)*4 + ks4][lane][j] = W[co = slab*64 + 4*(4*ks4 + j) + (lane >> 4)]
+//                                                   [ci = chunk*16 + (lane & 15)][t]
+__global__ __launch_bounds__(256) void dcn_bwd_wperm_kernel(const float* __restrict__ w, float4* __restrict__ wp,
+                                                            unsigned* __restrict__ wmax_bits, int Cin, int Cout,
+                                                            int NS, int total_f4) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  float mx = 0.f;
+  if (e < total_f4) {
+    const int lane = e & 63;
+    int r = e >> 6;
+    const int ks4 = r & 3;
+    r >>= 2;
+    const int t = r % TAPS;
+    r /= TAPS;
+    const int slab = r % NS, chunk = r / NS;
+    const int ci = chunk * KC + (lane & 15);
+    float v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int co = slab * 64 + 4 * (4 * ks4 + j) + (lane >> 4);
+      v[j] = (co < Cout && ci < Cin) ? w[((long long)co * Cin + ci) * TAPS + t] : 0.f;
+      mx = fmaxf(mx, fabsf(v[j]));
+    }
+    wp[e] = make_float4(v[0], v[1], v[2], v[3]);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  if ((threadIdx.x & 63) == 0 && mx > 0.f) atomicMax(wmax_bits, __float_as_uint(mx));   // positive floats order as uints
+}
+
+// ---- main kernel ---------------------------------------------------------------------------------
+// Schedule: every wave runs the matrix phase of a chunk (NS stages, one 64-channel weight slab each,
+// published by LDS-DMA into a double buffer behind ONE barrier per stage), then its consumption.  A
+// staggered variant (half the waves in the matrix phase while the other half consumes) was built and
+// measured equal within 2 %: on gfx950 the f32 MFMA executes on the SIMD's vector ALUs
+// (SQ_VALU_MFMA_COEXEC_CYCLES = 0 in every profile of this kernel), so the two phases of one SIMD never
+// overlap whichever waves run them.
+template <int CP, int TH, bool WANT_GX>
+__global__ __launch_bounds__(TH * 64) void dcn_bwd_data2_kernel(D2Args a) {
+  using G = Geo<TH>;
+  constexpr int RSZ = G::RSZ, RSZP = G::RSZP, RH = G::RH, NPX = G::NPX, NTHR = G::NTHR;
+  constexpr int NS = CP / 64;                              // 64-wide output-channel slabs
+  constexpr int NB = CP / 4;                               // B-operand registers per lane
+  __shared__ f32x4 Abuf[2][A_F4];                          // weights of one (chunk, slab), fragment order
+  __shared__ float xreg[KC * RSZP];                        // input region of the chunk's channels
+  __shared__ __attribute__((aligned(16))) unsigned long long gacc[WANT_GX ? KC * RSZP : 2];  // fixed-point grad_x region sums
+  __shared__ float4 rec[TAPS * NPX];                       // per (tap, pixel): ly, lx, mask, region index
+  __shared__ float wred[TH];
+
+  const unsigned long long t_entry = CP_T();
+  (void)t_entry;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lpx = lane & 15, g = lane >> 4;
+  const int b = blockIdx.y;
+  const int tyi = blockIdx.x / a.tpr, txi = blockIdx.x - tyi * a.tpr;
+  const int ty0 = tyi * TH, tx0 = txi * TW;
+  const int ry0 = ty0 - HALO, rx0 = tx0 - HALO_L;
+  const int HW = a.H * a.W;
+  const int py = ty0 + wid, pxx = tx0 + lpx;
+  const bool p_ok = py < a.H && pxx < a.W;
+  const int p = p_ok ? py * a.W + pxx : 0;
+  const int wpx = wid * TW + lpx;                          // pixel slot in the tile
+  const int cs0 = blockIdx.z * a.chunks_per_slice;
+  const int cs1 = min(a.chunks, cs0 + a.chunks_per_slice);
+  const int n = cs1 - cs0;
+
+  // ---- per (pixel, tap) sampling recipe into LDS; lane (px, g) builds taps g, g+4, g+8 ----
+  bool lane_fb = false;
+  float lane_mmax = 1.f;                                   // the bound of |gcol * m| also holds for masks > 1
+  {
+    const float* off = a.offset + (long long)b * a.offset_bstride;
+    const float* msk = a.mask + (long long)b * a.mask_bstride;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const int t = g + 4 * k;
+      if (t < TAPS) {
+        const int ky = t / 3, kx = t - ky * 3;
+        float oy = 0.f, ox = 0.f, m = 0.f;
+        if (p_ok) {
+          oy = off[(long long)(2 * t) * HW + p];
+          ox = off[(long long)(2 * t + 1) * HW + p];
+          m = msk[(long long)t * HW + p];
+          if (a.mask_is_logit) m = 1.f / (1.f + __expf(-m));
+        }
+        const float sy = (float)(py - a.pad + ky * a.dil) + oy;
+        const float sx = (float)(pxx - a.pad + kx * a.dil) + ox;
+        const bool inside = p_ok && sy > -1.f && sx > -1.f && sy < (float)a.H && sx < (float)a.W;
+        const float fy = floorf(sy), fx = floorf(sx);
+        const int y0 = (int)fy, x0 = (int)fx;
+        const bool y0ok = y0 >= 0, y1ok = y0 + 1 <= a.H - 1;
+        const bool x0ok = x0 >= 0, x1ok = x0 + 1 <= a.W - 1;
+        const int y0c = min(max(y0, 0), a.H - 1), x0c = min(max(x0, 0), a.W - 1);
+        const int vb = (y0ok && x0ok ? 1 : 0) | (y0ok && x1ok ? 2 : 0) | (y1ok && x0ok ? 4 : 0) |
+                       (y1ok && x1ok ? 8 : 0);
+        const int ry = y0 - ry0, rx = x0 - rx0;
+        const bool in_region = inside && ry >= 0 && ry + 1 < RH && rx >= 0 && rx + 1 < RWD;
+        // >= 0: region offset of the top-left corner; -2: contributes nothing; <= -3: cold path,
+        // packs the clamped top-left index and the corner validity bits
+        const int rb = in_region ? ry * RWD + rx : (inside ? -(3 + (((y0c * a.W + x0c) << 4) | vb)) : -2);
+        lane_fb |= rb <= -3;
+        lane_mmax = fmaxf(lane_mmax, fabsf(m));
+        rec[t * NPX + wpx] = make_float4(sy - fy, sx - fx, p_ok ? m : 0.f, __int_as_float(rb));
+      }
+    }
+  }
+  const bool any_fallback = __builtin_amdgcn_ballot_w64(lane_fb) != 0ull;
+  const unsigned long long t_rec = CP_T();
+  (void)t_rec;
+
+  // ---- B operand: this wave's 16 grad_out pixels, all output channels, in registers ----
+  const float* gob = a.go + (long long)b * a.Cout * HW;
+  const __amdgpu_buffer_rsrc_t rs_go = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(gob), 0, (int)((unsigned)a.Cout * (unsigned)HW * 4u), 0x00020000);
+  float breg[NB];
+  {
+    const unsigned gbase = p_ok ? ((unsigned)g * (unsigned)HW + (unsigned)p) * 4u : OOB;
+    const unsigned gstep = p_ok ? (unsigned)HW * 16u : 0u;          // 4 output channels
+#pragma unroll
+    for (int q = 0; q < NB; ++q)                                    // rows past Cout read 0
+      breg[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_go, gbase + (unsigned)q * gstep, 0, 0));
+  }
+  // fixed-point scale from a bound of |gcol|: max over the tile's pixels of sum_co |go| times max |W|
+  double fx_scale = 0.0, fx_inv = 0.0;
+  if (WANT_GX) {
+    float l1 = 0.f;
+#pragma unroll
+    for (int q = 0; q < NB; ++q) l1 += fabsf(breg[q]);
+    l1 += __shfl_xor(l1, 16, 64);
+    l1 += __shfl_xor(l1, 32, 64);
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) l1 = fmaxf(l1, __shfl_xor(l1, o, 64));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) lane_mmax = fmaxf(lane_mmax, __shfl_xor(lane_mmax, o, 64));
+    if (lane == 0) wred[wid] = l1 * lane_mmax;
+    for (int e = tid; e < KC * RSZP; e += NTHR) gacc[e] = 0ull;
+  }
+  const unsigned long long t_b0 = CP_T();
+  (void)t_b0;
+  __syncthreads();                                                  // rec, wred, gacc initialised
+  if (WANT_GX) {
+    float l1 = wred[0];
+#pragma unroll
+    for (int i = 1; i < TH; ++i) l1 = fmaxf(l1, wred[i]);
+    const float gb = l1 * a.wmax[0] * 1.0001f;
+    if (gb > 0.f && gb < 3.0e38f) {
+      int ge = 0;
+      (void)frexpf(gb, &ge);
+      fx_scale = ldexp(1.0, 35 - ge);
+      fx_inv = ldexp(1.0, ge - 35);
+    }
+  }
+
+  // ---- staging ----
+  // Weights: LDS-DMA (global_load_lds_dwordx4), no registers: a stage is 36 pieces of 1 KB (64 lanes x
+  // 16 B, fragment order = linear order), wave w moves pieces w, w+TH, ...; the DMA of stage j+1 is
+  // issued right behind the barrier that opens stage j and lands in the other buffer.
+  // Input region: the X waves fetch chunk i's cells into registers while they run MFMA(i) (their VALU
+  // is idle there and their register pressure low) and store them at the next odd boundary.
+  const unsigned plane_bytes = (unsigned)HW * 4u;
+  const float* xb = a.x + (long long)b * a.Cin * HW;
+  const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(xb), 0, (int)((unsigned)a.Cin * plane_bytes), 0x00020000);
+  constexpr int NPIECE = A_F4 / 64;                                 // 36
+  // (inline asm: the compiler does not know LDS-DMA targets only Abuf and would drain vmcnt before every
+  // LDS atomic of the consumption; the waits are placed by hand at the stage boundaries)
+  auto dma_a = [&](int stage_global, int buf) {
+    const f32x4* src = a.wp + (long long)stage_global * A_F4;
+#pragma unroll
+    for (int i = 0; i < (NPIECE + TH - 1) / TH; ++i) {
+      const int piece = wid + TH * i;
+      if (piece < NPIECE) {
+        const unsigned lds_addr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)(&Abuf[buf][piece * 64]);
+        const f32x4* gp = src + piece * 64 + lane;
+        asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds_addr), "v"(gp) : "memory", "m0");
+      }
+    }
+  };
+  constexpr int NXT = NTHR;                                         // threads that stage the input region
+  constexpr int XRX = (KC * RSZ + NXT - 1) / NXT;                   // region cells per X thread
+  float xr[XRX];
+  auto load_x = [&](int ch) {                                       // X waves only
+    const unsigned cbase = (unsigned)(ch * KC) * plane_bytes;       // rides in voffset (range-checked);
+#pragma unroll                                                      // OOB + cbase stays past the tensor
+    for (int i = 0; i < XRX; ++i) {
+      int e = tid + NXT * i;
+      asm volatile("" : "+v"(e));                                   // keep the index math out of the loop-invariant set
+      const int c = e / RSZ, cell = e - c * RSZ;
+      const int ry = cell / RWD, rx = cell - ry * RWD;
+      const int gy_ = ry0 + ry, gx_ = rx0 + rx;
+      const bool ok = e < KC * RSZ && gy_ >= 0 && gy_ < a.H && gx_ >= 0 && gx_ < a.W;
+      const unsigned off = ok ? (unsigned)c * plane_bytes + 4u * (unsigned)(gy_ * a.W + gx_) : OOB;
+      xr[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_x, off + cbase, 0, 0));
+    }
+  };
+  auto store_x = [&]() {                                            // X waves only
+#pragma unroll
+    for (int i = 0; i < XRX; ++i) {
+      int e = tid + NXT * i;
+      asm volatile("" : "+v"(e));
+      const int c = e / RSZ;
+      if (e < KC * RSZ) xreg[c * RSZP + (e - c * RSZ)] = xr[i];
+    }
+  };
+
+  float gm[TAPS], gy[TAPS], gxo[TAPS];
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t) gm[t] = gy[t] = gxo[t] = 0.f;
+  const int cbase_lds = 4 * g * RSZP;                               // this lane's first channel in the regions
+  float* slab_tile = WANT_GX ? a.slab + ((long long)(b * a.ntiles + blockIdx.x) * a.Cin) * RSZ : nullptr;
+  constexpr int NQ = KC * RSZ / 4;                                  // 4-cell groups of the chunk's regions
+  constexpr int XQ = (NQ + NTHR - 1) / NTHR;
+  static_assert(RSZ % 4 == 0 && RSZP % 4 == 0, "flush moves aligned groups of four cells");
+  auto flush = [&](int c0) {                                        // region sums -> slab, plain coalesced stores
+    float* dst = slab_tile + (long long)c0 * RSZ;
+#pragma unroll
+    for (int i = 0; i < XQ; ++i) {
+      int q = tid + NTHR * i;
+      asm volatile("" : "+v"(q));                                   // keep the index math out of the loop-invariant set
+      if (q < NQ) {
+        const int c = q / (RSZ / 4);
+        const int l = c * RSZP + (q - c * (RSZ / 4)) * 4;
+        typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+        u64x2* gp = reinterpret_cast<u64x2*>(&gacc[l]);
+        const u64x2 a0 = gp[0], a1 = gp[1];
+        gp[0] = u64x2{0ull, 0ull};
+        gp[1] = u64x2{0ull, 0ull};
+        f32x4 o;
+        o.x = (float)((double)(((long long)(a0.x << 16)) >> 16) * fx_inv);   // low 48 bits, sign-extended
+        o.y = (float)((double)(((long long)(a0.y << 16)) >> 16) * fx_inv);
+        o.z = (float)((double)(((long long)(a1.x << 16)) >> 16) * fx_inv);
+        o.w = (float)((double)(((long long)(a1.y << 16)) >> 16) * fx_inv);
+        if (c0 + c < a.Cin) *reinterpret_cast<f32x4*>(dst + 4 * q) = o;
+      }
+    }
+  };
+
+  f32x4 acc[TAPS];
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (n > 0) dma_a(cs0 * NS, 0);
+  int stage = 0;                                                    // counts published weight stages
+  unsigned long long t_mfma = 0, t_cons = 0, t_bodd = 0, t_bar = 0, t_flush = 0, t_kernel0 = CP_T();
+  (void)t_mfma; (void)t_cons; (void)t_bodd; (void)t_bar; (void)t_flush; (void)t_kernel0;   // (diagnostic build only)
+
+  auto mfma_slab = [&](auto S_, int buf) __attribute__((always_inline)) {
+    constexpr int s = decltype(S_)::value;
+#pragma unroll
+    for (int ks4 = 0; ks4 < 4; ++ks4) {
+#pragma unroll
+      for (int t0 = 0; t0 < TAPS; t0 += 3) {
+        f32x4 af[3];
+#pragma unroll
+        for (int u = 0; u < 3; ++u) af[u] = Abuf[buf][((t0 + u) * 4 + ks4) * 64 + lane];
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+          acc[t0 + u] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[u].x, breg[s * 16 + ks4 * 4 + 0], acc[t0 + u], 0, 0, 0);
+          acc[t0 + u] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[u].y, breg[s * 16 + ks4 * 4 + 1], acc[t0 + u], 0, 0, 0);
+          acc[t0 + u] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[u].z, breg[s * 16 + ks4 * 4 + 2], acc[t0 + u], 0, 0, 0);
+          acc[t0 + u] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[u].w, breg[s * 16 + ks4 * 4 + 3], acc[t0 + u], 0, 0, 0);
+        }
+      }
+    }
+  };
+  // Consumption segment s of a chunk: lane = (pixel lpx, channels c0 + 4g .. 4g+3), one tap at a time.
+  // The region indices of the segment's taps are read first, so the corner reads of tap t+1 depend on no
+  // LDS read and are issued AHEAD of tap t's adds (LDS operations of a wave complete in order: a read
+  // queued behind sixteen adds would make the wave wait for all of them).
+  auto consume_seg = [&](auto S_, int c0_cons) __attribute__((always_inline)) {
+    constexpr int s = decltype(S_)::value;
+    constexpr int T0 = (TAPS * s + NS - 1) / NS, T1 = (TAPS * (s + 1) + NS - 1) / NS;
+    int rbs[T1 - T0];
+#pragma unroll
+    for (int t = T0; t < T1; ++t) rbs[t - T0] = __float_as_int(rec[t * NPX + wpx].w);
+    float4 rcb[2];                                                  // recipe and corners of taps t (slot t & 1) and t+1
+    float vb_[2][4][4];
+    auto fetch = [&](int t, int slot) __attribute__((always_inline)) {
+      rcb[slot] = rec[t * NPX + wpx];
+      const int rbc = max(rbs[t - T0], 0) + cbase_lds;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        vb_[slot][r][0] = xreg[rbc + r * RSZP];
+        vb_[slot][r][1] = xreg[rbc + r * RSZP + 1];
+        vb_[slot][r][2] = xreg[rbc + r * RSZP + RWD];
+        vb_[slot][r][3] = xreg[rbc + r * RSZP + RWD + 1];
+      }
+    };
+    fetch(T0, T0 & 1);
+#pragma unroll
+    for (int t = T0; t < T1; ++t) {
+      const float ly = rcb[t & 1].x, lx = rcb[t & 1].y, m = rcb[t & 1].z;
+      const int rb = rbs[t - T0];
+      const float (&v)[4][4] = vb_[t & 1];
+      if (t + 1 < T1) fetch(t + 1, (t + 1) & 1);
+      __builtin_amdgcn_sched_barrier(0);                            // keep those reads ahead of the adds below
+      if (rb >= 0) {                                                // out-of-image cells of the region hold 0
+        const float hy = 1.f - ly, hx = 1.f - lx;
+        const float w00 = hy * hx, w01 = hy * lx, w10 = ly * hx, w11 = ly * lx;
+        double d00 = 0., d01 = 0., d10 = 0., d11 = 0.;
+        if (WANT_GX) {
+          d00 = (double)w00 * fx_scale;
+          d01 = (double)w01 * fx_scale;
+          d10 = (double)w10 * fx_scale;
+          d11 = (double)w11 * fx_scale;
+        }
+        const int cell = cbase_lds + rb;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float gc = acc[t][r];
+          const float v00 = v[r][0], v01 = v[r][1], v10 = v[r][2], v11 = v[r][3];
+          gm[t] += gc * (w00 * v00 + w01 * v01 + w10 * v10 + w11 * v11);
+          const float gcm = gc * m;
+          gy[t] += gcm * (hx * (v10 - v00) + lx * (v11 - v01));
+          gxo[t] += gcm * (hy * (v01 - v00) + ly * (v11 - v10));
+          if (WANT_GX) {                                            // cells outside the image are never read back
+            const double dg = (double)gcm;
+            unsigned long long* q = &gacc[cell + r * RSZP];
+            atomicAdd(q, (unsigned long long)__double_as_longlong(fma(dg, d00, FX_MAGIC)));
+            atomicAdd(q + 1, (unsigned long long)__double_as_longlong(fma(dg, d01, FX_MAGIC)));
+            atomicAdd(q + RWD, (unsigned long long)__double_as_longlong(fma(dg, d10, FX_MAGIC)));
+            atomicAdd(q + RWD + 1, (unsigned long long)__double_as_longlong(fma(dg, d11, FX_MAGIC)));
+          }
+        }
+      }
+    }
+    // cold path (skipped wave-uniformly when no pixel of the wave has such a tap): corners that leave the
+    // region are gathered from memory, their grad_x contributions go there as float atomics
+    if (s == NS - 1 && any_fallback) {
+#pragma unroll
+      for (int t = 0; t < TAPS; ++t) {                              // static t: acc / gm stay in registers
+        const float4 rc = rec[t * NPX + wpx];
+        const int rb = __float_as_int(rc.w);
+        if (rb <= -3) {
+          const int code = -rb - 3;
+          const unsigned vb = (unsigned)(code & 15);
+          const int fbase = code >> 4;
+          const int dx = ((vb & 3u) == 3u || (vb & 12u) == 12u) ? 1 : 0;
+          const int dy = ((vb & 5u) == 5u || (vb & 10u) == 10u) ? a.W : 0;
+          const float ly = rc.x, lx = rc.y, m = rc.z, hy = 1.f - ly, hx = 1.f - lx;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int c = c0_cons + 4 * g + r;
+            if (c < a.Cin) {
+              const float* q = xb + (long long)c * HW + fbase;
+              const float v00 = (vb & 1u) ? q[0] : 0.f;
+              const float v01 = (vb & 2u) ? q[dx] : 0.f;
+              const float v10 = (vb & 4u) ? q[dy] : 0.f;
+              const float v11 = (vb & 8u) ? q[dy + dx] : 0.f;
+              const float gc = acc[t][r];
+              gm[t] += gc * (hy * hx * v00 + hy * lx * v01 + ly * hx * v10 + ly * lx * v11);
+              const float gcm = gc * m;
+              gy[t] += gcm * (hx * (v10 - v00) + lx * (v11 - v01));
+              gxo[t] += gcm * (hy * (v01 - v00) + ly * (v11 - v10));
+              if (WANT_GX && a.gx) {
+                float* o = a.gx + ((long long)b * a.Cin + c) * HW + fbase;
+                if (vb & 1u) atomicAdd(o, gcm * hy * hx);
+                if (vb & 2u) atomicAdd(o + dx, gcm * hy * lx);
+                if (vb & 4u) atomicAdd(o + dy, gcm * ly * hx);
+                if (vb & 8u) atomicAdd(o + dy + dx, gcm * ly * lx);
+              }
+            }
+          }
+        }
+      }
+    }
+  };
+  {
+    for (int i = 0; i < n; ++i) {
+#pragma unroll
+      for (int t = 0; t < TAPS; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const unsigned long long tw0 = CP_T();
+      (void)tw0;
+      load_x(cs0 + i);                                              // lands during the matrix phase
+      static_for<0, NS>([&](auto S_) __attribute__((always_inline)) {
+        constexpr int s = decltype(S_)::value;
+        const int buf = stage & 1;
+        __builtin_amdgcn_s_waitcnt(0x0f70);                         // vmcnt(0): this stage's DMA (and the region loads)
+        __syncthreads();                                            // ... of every wave; previous consumption finished
+        const int ni = s + 1 < NS ? i : i + 1, ns = s + 1 < NS ? s + 1 : 0;
+        if (ni < n) dma_a((cs0 + ni) * NS + ns, buf ^ 1);
+        ++stage;
+        mfma_slab(S_, buf);
+      });
+      CP_ACC(t_mfma, tw0);
+      const unsigned long long tf0 = CP_T();
+      (void)tf0;
+      store_x();                                                    // (loads waited for at the stage barrier above)
+      if (WANT_GX && i >= 1) flush((cs0 + i - 1) * KC);
+      __syncthreads();                                              // region + emptied sums visible
+      CP_ACC(t_flush, tf0);
+      const unsigned long long tw1 = CP_T();
+      (void)tw1;
+      static_for<0, NS>([&](auto S_) __attribute__((always_inline)) { consume_seg(S_, (cs0 + i) * KC); });
+      CP_ACC(t_cons, tw1);
+    }
+  }
+  if (WANT_GX && n > 0) {
+    __syncthreads();                                                // the last chunk's adds are in LDS
+    flush((cs1 - 1) * KC);
+  }
+
+#ifdef CP_STAMP
+  if (a.dbg && lane == 0 && blockIdx.y == 0 && blockIdx.z == 0 && blockIdx.x < 1024) {
+    unsigned long long* d = a.dbg + ((long long)blockIdx.x * TH + wid) * 8;
+    d[0] = t_mfma; d[1] = t_cons; d[2] = t_bodd; d[3] = t_bar; d[4] = t_flush; d[5] = CP_T() - t_kernel0;
+    d[6] = t_rec - t_entry; d[7] = t_kernel0 - t_b0;
+    if (wid == 0) { d[8 + 6] = t_b0 - t_rec; d[8 + 7] = t_entry; }   // (wave 1's slots 6/7 reused: breg phase, entry time)
+  }
+  if (a.dbg && lane == 0 && wid == 0 && blockIdx.z == 0) {           // every workgroup: entry, exit, hardware id
+    unsigned long long* d = a.dbg + 1024 * 8 * 8 + ((long long)blockIdx.y * gridDim.x + blockIdx.x) * 4;
+    unsigned hwid;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    d[0] = t_entry; d[1] = CP_T(); d[2] = hwid; d[3] = xcc;
+  }
+#endif
+  // ---- grad_offset / grad_mask: add the four channel groups of each pixel, lane g stores taps g, g+4, g+8 ----
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t) {
+    gm[t] += __shfl_xor(gm[t], 16, 64);
+    gm[t] += __shfl_xor(gm[t], 32, 64);
+    gy[t] += __shfl_xor(gy[t], 16, 64);
+    gy[t] += __shfl_xor(gy[t], 32, 64);
+    gxo[t] += __shfl_xor(gxo[t], 16, 64);
+    gxo[t] += __shfl_xor(gxo[t], 32, 64);
+  }
+  if (p_ok) {
+    float* goffb = a.goff ? a.goff + (long long)blockIdx.z * a.part_sstride + (long long)b * a.goff_bstride : nullptr;
+    float* gmaskb = a.gmask ? a.gmask + (long long)blockIdx.z * a.part_sstride + (long long)b * a.gmask_bstride : nullptr;
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t) {
+      if ((t & 3) != g) continue;
+      if (goffb) {
+        goffb[(long long)(2 * t) * HW + p] = gy[t];
+        goffb[(long long)(2 * t + 1) * HW + p] = gxo[t];
+      }
+      if (gmaskb) {
+        float v = gm[t];
+        if (a.mask_is_logit) {
+          const float m = rec[t * NPX + wpx].z;
+          v *= m * (1.f - m);
+        }
+        gmaskb[(long long)t * HW + p] = v;
+      }
+    }
+  }
+}
+
+// ---- grad_x[b][c][y][x] += sum of the slabs whose region covers (y, x), fixed order -------------
+// A tile's slab holds, per channel, RH rows of 24 cells: columns 0..3 = left halo, 4..19 = the tile's
+// own pixels (16-byte aligned), 20..23 = right halo; rows 0..2 / RH-3..RH-1 = the vertical halos.  One
+// thread adds up one float4 of grad_x: its own tile's cells, the horizontal neighbour's halo when it is
+// the tile's first / last float4, the vertical neighbours' for the tile's first / last three rows, and
+// the diagonal ones.
+template <bool VEC>
+__global__ __launch_bounds__(256) void dcn_bwd_gx_reduce_kernel(const float* __restrict__ slab, float* __restrict__ gx,
+                                                                int BC, int Cin, int H, int W, int tpr, int tpc,
+                                                                int TH) {
+  constexpr int V = VEC ? 4 : 1;
+  const int xq = blockIdx.x * 64 + (threadIdx.x & 63);              // float4 (or pixel) index in the row
+  const int x = xq * V;
+  const int y = blockIdx.y;
+  const int bc = blockIdx.z * 4 + (threadIdx.x >> 6);               // b * Cin + c
+  if (x >= W || bc >= BC) return;
+  const int b = bc / Cin, c = bc - b * Cin;
+  const int RH = TH + 2 * HALO, RSZ = RH * RWD;
+  const int txi = x / TW, tyi = y / TH;
+  const int ntiles = tpr * tpc;
+  float s[V];
+#pragma unroll
+  for (int i = 0; i < V; ++i) s[i] = 0.f;
+#pragma unroll
+  for (int dy = 0; dy <= 2; ++dy) {                                 // own tile first, then above, then below
+    const int tyy = tyi + (dy == 0 ? 0 : (dy == 1 ? -1 : 1));
+    const int ry = y - (tyy * TH - HALO);
+    if (tyy < 0 || tyy >= tpc || ry < 0 || ry >= RH) continue;
+#pragma unroll
+    for (int dx = 0; dx <= 2; ++dx) {
+      const int txx = txi + (dx == 0 ? 0 : (dx == 1 ? -1 : 1));
+      const int rx = x - (txx * TW - HALO_L);
+      if (txx < 0 || txx >= tpr || rx < 0 || rx + V > RWD) continue;
+      const float* q = slab + (((long long)b * ntiles + tyy * tpr + txx) * Cin + c) * RSZ + ry * RWD + rx;
+      if (VEC) {
+        const float4 v = *reinterpret_cast<const float4*>(q);
+        s[0] += v.x; s[1 % V] += v.y; s[2 % V] += v.z; s[3 % V] += v.w;
+      } else {
+        s[0] += q[0];
+      }
+    }
+  }
+  float* o = gx + ((long long)bc * H + y) * W + x;
+  if (VEC) {
+    float4 v = *reinterpret_cast<float4*>(o);
+    v.x += s[0]; v.y += s[1 % V]; v.z += s[2 % V]; v.w += s[3 % V];
+    *reinterpret_cast<float4*>(o) = v;
+  } else {
+    o[0] += s[0];
+  }
+}
+
+// ---- out[b][ch][p] = sum_s part[s][b][ch][p]  (channel-sliced launches) -------------------------
+__global__ __launch_bounds__(256) void dcn_bwd_part_reduce_kernel(const float* __restrict__ part, long long sstride,
+                                                                  int slices, float* __restrict__ goff,
+                                                                  long long goff_bstride, float* __restrict__ gmask,
+                                                                  long long gmask_bstride, int B, int HW) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;     // over B * 27 * HW
+  const long long per_b = 27ll * HW;
+  if (i >= (long long)B * per_b) return;
+  const int b = (int)(i / per_b);
+  const long long r = i - (long long)b * per_b;
+  const int ch = (int)(r / HW);
+  const int p = (int)(r - (long long)ch * HW);
+  float s = 0.f;
+  for (int k = 0; k < slices; ++k) s += part[(long long)k * sstride + i];
+  if (ch < 18) {
+    if (goff) goff[(long long)b * goff_bstride + (long long)ch * HW + p] = s;
+  } else if (gmask) {
+    gmask[(long long)b * gmask_bstride + (long long)(ch - 18) * HW + p] = s;
+  }
+}
+
+constexpr int TH_DEFAULT = 8;
+
+struct D2Plan {
+  int tpr, tpc, ntiles, chunks, NS, slices, chunks_per_slice;
+  size_t off_wmax, off_wp, off_slab, off_part, total;
+};
+
+}  // namespace
+
+// Shapes the kernel takes: stride 1, output size = input size (pad == dil), Cout <= 256,
+// 32-bit byte offsets inside one image.
+bool cp_dcn_bwd_data2_supported(const cp_dcn_shape* s) {
+  if (s->stride != 1 || s->pad != s->dil || s->kh != 3 || s->kw != 3 || s->Cout > 256) return false;
+  const unsigned long long hw = (unsigned long long)s->H * s->W;
+  const unsigned long long cin_pad = (unsigned long long)((s->Cin + KC - 1) / KC * KC);
+  if (hw >= (1ull << 27)) return false;                              // cold-path index packed with 4 bits
+  if (cin_pad * hw * 4ull >= 0x70000000ull) return false;            // OOB + chunk base must not wrap
+  if (256ull * hw * 4ull >= 0x70000000ull) return false;
+  if (s->B > 65535) return false;
+  return true;
+}
+
+static D2Plan d2_plan(const cp_dcn_shape* s, bool want_gx, bool want_om) {
+  D2Plan p;
+  p.tpr = (s->W + TW - 1) / TW;
+  p.tpc = (s->H + TH_DEFAULT - 1) / TH_DEFAULT;
+  p.ntiles = p.tpr * p.tpc;
+  p.chunks = (s->Cin + KC - 1) / KC;
+  p.NS = s->Cout <= 64 ? 1 : (s->Cout <= 128 ? 2 : 4);
+  // channel slices: at least ~3 rounds of workgroups on 256 CUs (one workgroup per CU)
+  const long long wgs = (long long)p.ntiles * s->B;
+  int slices = (int)((768 + wgs - 1) / wgs);
+  if (slices < 1) slices = 1;
+  if (slices > p.chunks) slices = p.chunks;
+  p.chunks_per_slice = (p.chunks + slices - 1) / slices;
+  p.slices = (p.chunks + p.chunks_per_slice - 1) / p.chunks_per_slice;
+  size_t o = 0;
+  p.off_wmax = o; o += 256;
+  p.off_wp = o; o += cp_align_up((size_t)p.chunks * p.NS * A_F4 * sizeof(f32x4), 256);
+  p.off_slab = o;
+  if (want_gx) o += cp_align_up((size_t)s->B * p.ntiles * s->Cin * Geo<TH_DEFAULT>::RSZ * sizeof(float), 256);
+  p.off_part = o;
+  if (want_om && p.slices > 1) o += cp_align_up((size_t)p.slices * s->B * 27 * s->H * s->W * sizeof(float), 256);
+#ifdef CP_STAMP
+  o += 1024 * 16 * 8 * 8;
+#endif
+  p.total = o;
+  return p;
+}
+
+size_t cp_dcn_bwd_data2_workspace_bytes(const cp_dcn_shape* s) {
+  return cp_dcn_bwd_data2_supported(s) ? d2_plan(s, true, true).total : 0;
+}
+
+template <int CP, bool WANT_GX>
+static void d2_launch(const D2Args& a, const D2Plan& p, int B, hipStream_t st) {
+  hipLaunchKernelGGL((dcn_bwd_data2_kernel<CP, TH_DEFAULT, WANT_GX>), dim3(p.ntiles, B, p.slices),
+                     dim3(TH_DEFAULT * 64), 0, st, a);
+}
+
+// Data gradients of cp_dcn_v2_backward on the caller's workspace.  Returns CP_OK, or CP_EINVAL when
+// the workspace is too small.
+int cp_dcn_bwd_data2(const cp_dcn_shape* s, const float* x, const float* offset, int64_t offset_bstride,
+                     const float* mask, int64_t mask_bstride, int32_t mask_is_logit, const float* weight,
+                     const float* grad_out, float* grad_x, float* grad_offset, int64_t grad_offset_bstride,
+                     float* grad_mask, int64_t grad_mask_bstride, void* workspace, size_t workspace_bytes,
+                     hipStream_t st) {
+  const bool want_gx = grad_x != nullptr, want_om = grad_offset != nullptr || grad_mask != nullptr;
+  const D2Plan p = d2_plan(s, want_gx, want_om);
+  if (!workspace || workspace_bytes < p.total) return CP_EINVAL;
+  char* ws = (char*)workspace;
+  unsigned* wmax_bits = (unsigned*)(ws + p.off_wmax);
+  f32x4* wp = (f32x4*)(ws + p.off_wp);
+  (void)hipMemsetAsync(wmax_bits, 0, 4, st);
+  const int total_f4 = p.chunks * p.NS * A_F4;
+  hipLaunchKernelGGL(dcn_bwd_wperm_kernel, dim3((total_f4 + 255) / 256), dim3(256), 0, st, weight, (float4*)wp, wmax_bits,
+                     s->Cin, s->Cout, p.NS, total_f4);
+  const int HW = s->H * s->W;
+  D2Args a;
+  a.x = x; a.offset = offset; a.mask = mask; a.go = grad_out; a.wp = wp; a.wmax = (const float*)wmax_bits;
+  a.gx = grad_x; a.slab = want_gx ? (float*)(ws + p.off_slab) : nullptr;
+  a.offset_bstride = offset_bstride; a.mask_bstride = mask_bstride;
+  a.B = s->B; a.Cin = s->Cin; a.H = s->H; a.W = s->W; a.Cout = s->Cout;
+  a.pad = s->pad; a.dil = s->dil; a.mask_is_logit = mask_is_logit;
+  a.tpr = p.tpr; a.ntiles = p.ntiles; a.chunks = p.chunks; a.chunks_per_slice = p.chunks_per_slice;
+#ifdef CP_STAMP
+  a.dbg = (unsigned long long*)(ws + p.total - 1024 * 16 * 8 * 8);
+#endif
+  float* part = (float*)(ws + p.off_part);
+  if (p.slices > 1 && want_om) {           // partial sums [slice][B][27][HW]: offsets at ch 0, mask at ch 18
+    a.goff = part; a.gmask = part + 18ll * HW;
+    a.goff_bstride = a.gmask_bstride = 27ll * HW;
+    a.part_sstride = (long long)s->B * 27 * HW;
+  } else {
+    a.goff = grad_offset; a.gmask = grad_mask;
+    a.goff_bstride = grad_offset_bstride; a.gmask_bstride = grad_mask_bstride;
+    a.part_sstride = 0;
+  }
+  if (want_gx) {
+    if (p.NS == 1) d2_launch<64, true>(a, p, s->B, st);
+    else if (p.NS == 2) d2_launch<128, true>(a, p, s->B, st);
+    else d2_launch<256, true>(a, p, s->B, st);
+    const bool vec = s->W % 4 == 0 && ((uintptr_t)grad_x & 15) == 0;
+    const int per_row = vec ? s->W / 4 : s->W;
+    const dim3 grid((per_row + 63) / 64, s->H, (s->B * s->Cin + 3) / 4);
+    if (vec)
+      hipLaunchKernelGGL(dcn_bwd_gx_reduce_kernel<true>, grid, dim3(256), 0, st, a.slab, grad_x, s->B * s->Cin, s->Cin,
+                         s->H, s->W, p.tpr, p.tpc, TH_DEFAULT);
+    else
+      hipLaunchKernelGGL(dcn_bwd_gx_reduce_kernel<false>, grid, dim3(256), 0, st, a.slab, grad_x, s->B * s->Cin, s->Cin,
+                         s->H, s->W, p.tpr, p.tpc, TH_DEFAULT);
+  } else {
+    if (p.NS == 1) d2_launch<64, false>(a, p, s->B, st);
+    else if (p.NS == 2) d2_launch<128, false>(a, p, s->B, st);
+    else d2_launch<256, false>(a, p, s->B, st);
+  }
+  if (p.slices > 1 && want_om) {
+    const long long n = (long long)s->B * 27 * HW;
+    hipLaunchKernelGGL(dcn_bwd_part_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, part,
+                       a.part_sstride, p.slices, grad_offset, (long long)grad_offset_bstride, grad_mask,
+                       (long long)grad_mask_bstride, s->B, HW);
+  }
+  return cp_launch_status();
+}

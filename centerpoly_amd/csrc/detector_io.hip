@@ -144,3 +144,105 @@ extern "C" int cp_preprocess_warp_normalize(const uint8_t* src, int32_t src_h, i
                      (hipStream_t)stream, a);
   return cp_launch_status();
 }
+
+// ------------------------------------------------------ training-input colour augmentation ---
+// color_aug + normalise of the training sampler (src/lib/datasets/sample/polydet.py:128-136,
+// src/lib/utils/image.py:231-264) on the warped input, in place on BGR planes holding x / 255:
+//   gs = grey(image), gs_mean = mean(gs)                       (taken ONCE, before any op)
+//   three ops in a random order: brightness  x *= a
+//                                contrast    x = x * a + gs_mean * (1 - a)
+//                                saturation  x = x * a + gs * (1 - a)
+//   lighting   x += eig_vec . (eig_val * alpha)   (a per-channel constant, added in float64)
+//   normalise  x = (x - mean) / std
+// float32 operations in numpy's order, no fma contraction.  Two kernels: grey-level sum (double
+// partials), then one streaming pass.
+namespace {
+constexpr int CA_BLOCKS = 1024;
+
+__global__ __launch_bounds__(256) void color_gs_sum_kernel(const float* __restrict__ img, long long HW,
+                                                           double* __restrict__ part) {
+  double s = 0.0;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < HW; i += (long long)gridDim.x * 256) {
+    const float g = __fadd_rn(__fadd_rn(__fmul_rn(img[i], 0.114f), __fmul_rn(img[HW + i], 0.587f)),
+                              __fmul_rn(img[2 * HW + i], 0.299f));
+    s += (double)g;
+  }
+  s = cp_wave_sum_d(s);
+  __shared__ double red[4];
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+struct ColorArgs {
+  float* img;
+  long long HW;
+  const double* part;
+  int nparts;
+  int order[3];
+  float alpha[3];
+  double light[3];
+  float mean[3], stdv[3];
+  int color_on;
+};
+
+__global__ __launch_bounds__(256) void color_apply_kernel(ColorArgs a) {
+  __shared__ float s_mean;
+  if (a.color_on) {
+    double s = 0.0;
+    for (int i = threadIdx.x; i < a.nparts; i += 256) s += a.part[i];
+    s = cp_wave_sum_d(s);
+    __shared__ double red[4];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) s_mean = (float)((red[0] + red[1] + red[2] + red[3]) / (double)a.HW);
+    __syncthreads();
+  }
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= a.HW) return;
+  float v[3] = {a.img[i], a.img[a.HW + i], a.img[2 * a.HW + i]};
+  if (a.color_on) {
+    const float gs = __fadd_rn(__fadd_rn(__fmul_rn(v[0], 0.114f), __fmul_rn(v[1], 0.587f)), __fmul_rn(v[2], 0.299f));
+    const float gmean = s_mean;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const float al = a.alpha[k];
+      const float other = a.order[k] == 1 ? __fmul_rn(gmean, 1.f - al) : __fmul_rn(gs, 1.f - al);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        v[c] = __fmul_rn(v[c], al);
+        if (a.order[k] != 0) v[c] = __fadd_rn(v[c], other);
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) v[c] = (float)((double)v[c] + a.light[c]);
+  }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) a.img[c * a.HW + i] = __fdiv_rn(__fsub_rn(v[c], a.mean[c]), a.stdv[c]);
+}
+}  // namespace
+
+extern "C" size_t cp_color_aug_workspace_bytes(void) { return CA_BLOCKS * sizeof(double); }
+
+extern "C" int cp_color_aug_normalize(float* img, int64_t HW, int32_t color_on, const int32_t* order,
+                                      const float* alpha, const double* light, const float* mean,
+                                      const float* stdv, void* workspace, size_t workspace_bytes, void* stream) {
+  CP_CHECK_ARG(img && mean && stdv && HW > 0);
+  ColorArgs a;
+  a.img = img; a.HW = HW; a.color_on = color_on ? 1 : 0;
+  a.part = (const double*)workspace; a.nparts = 0;
+  for (int c = 0; c < 3; ++c) { a.mean[c] = mean[c]; a.stdv[c] = stdv[c]; a.order[c] = 0; a.alpha[c] = 1.f; a.light[c] = 0.0; }
+  hipStream_t st = (hipStream_t)stream;
+  if (color_on) {
+    CP_CHECK_ARG(order && alpha && light && workspace && workspace_bytes >= cp_color_aug_workspace_bytes());
+    for (int c = 0; c < 3; ++c) {
+      CP_CHECK_ARG(order[c] >= 0 && order[c] <= 2);
+      a.order[c] = order[c]; a.alpha[c] = alpha[c]; a.light[c] = light[c];
+    }
+    long long nb = (HW + 255) / 256;
+    a.nparts = (int)(nb < CA_BLOCKS ? nb : CA_BLOCKS);
+    hipLaunchKernelGGL(color_gs_sum_kernel, dim3(a.nparts), dim3(256), 0, st, img, (long long)HW, (double*)workspace);
+  }
+  hipLaunchKernelGGL(color_apply_kernel, dim3((unsigned)((HW + 255) / 256)), dim3(256), 0, st, a);
+  return cp_launch_status();
+}

@@ -82,3 +82,113 @@ def build_targets(raw, output_h, output_w, num_classes, rep="cartesian", no_reor
     if not with_border_hm:
         del out["border_hm"]
     return out
+
+
+class PolydetDataset(object):
+    """Sampler mixed into a dataset class by get_dataset (reference: PolydetDataset.__getitem__,
+    src/lib/datasets/sample/polydet.py:66-449), split between host and device:
+
+      loader worker (here)   read the image, draw the augmentation (scale / centre / flip / colour
+                             parameters, in the reference's order of random calls), mirror the 8-bit
+                             image when flipped, pack the raw annotations -- no per-pixel arithmetic
+      GPU (PolydetTrainer.prepare_batch)   cv2-style warp to the network input
+                             (cp_preprocess_warp_normalize), colour augmentation + normalisation
+                             (cp_color_aug_normalize), all training targets (cp_polydet_targets)
+
+    Items of one batch must have equal image sizes (true for Cityscapes / KITTI crops of one size)."""
+
+    def _get_border(self, border, size):
+        i = 1
+        while size - border // i <= border // i:
+            i *= 2
+        return border // i
+
+    def __getitem__(self, index):
+        import random
+
+        from ...utils.image import color_aug_params, get_affine_transform
+        opt = self.opt
+        img_id = self.images[index]
+        info = self.coco.loadImgs(ids=[img_id])[0]
+        anns = self.coco.loadAnns(ids=self.coco.getAnnIds(imgIds=[img_id]))
+        img = self.read_image(info["file_name"])
+        height, width = img.shape[0], img.shape[1]
+        c = np.array([width / 2.0, height / 2.0], dtype=np.float32)
+        if opt.keep_res:
+            input_h, input_w = (height | opt.pad) + 1, (width | opt.pad) + 1
+            s = np.array([input_w, input_h], dtype=np.float32)
+        else:
+            s = max(height, width) * 1.0
+            input_h, input_w = opt.input_h, opt.input_w
+        flipped = False
+        if self.split == "train":
+            if not opt.not_rand_crop:
+                s = s * np.random.choice(np.arange(0.6, 1.4, 0.1))
+                w_border = self._get_border(128, width)
+                h_border = self._get_border(128, height)
+                c[0] = np.random.randint(low=w_border, high=width - w_border)
+                c[1] = np.random.randint(low=h_border, high=height - h_border)
+            else:
+                sf, cf = opt.scale, opt.shift
+                c[0] += s * np.clip(np.random.randn() * cf, -2 * cf, 2 * cf)
+                c[1] += s * np.clip(np.random.randn() * cf, -2 * cf, 2 * cf)
+                s = s * np.clip(np.random.randn() * sf + 1, 1 - sf, 1 + sf)
+            if np.random.random() < opt.flip:
+                flipped = True
+                img = np.ascontiguousarray(img[:, ::-1, :])
+                c[0] = width - c[0] - 1
+        trans_input = get_affine_transform(c, s, 0, [input_w, input_h])
+        color = np.zeros(10, dtype=np.float64)                 # [on, order x3, alpha x3, light x3]
+        if self.split == "train" and not opt.no_color_aug:
+            order, alphas, light = color_aug_params(self._data_rng, random)
+            color[0] = 1.0
+            color[1:4] = order
+            color[4:7] = alphas
+            color[7:10] = np.dot(self._eig_vec.astype(np.float64), self._eig_val.astype(np.float64) * light)
+        output_h, output_w = input_h // opt.down_ratio, input_w // opt.down_ratio
+        trans_output = get_affine_transform(c, s, 0, [output_w, output_h])
+        packed_anns = []
+        for a in anns[:self.max_objs]:
+            packed_anns.append({"bbox": [a["bbox"][0], a["bbox"][1], a["bbox"][0] + a["bbox"][2],
+                                         a["bbox"][1] + a["bbox"][3]],
+                                "poly": a["poly"], "cls_id": int(self.cat_ids[a["category_id"]]),
+                                "pseudo_depth": a.get("pseudo_depth", 0),
+                                "freq": self.class_frequencies[self.class_name[a["category_id"]]]})
+        item = pack_annotations(packed_anns, trans_output, flipped, width, self.max_objs, opt.nbr_points)
+        item["image_u8"] = img
+        item["trans_input"] = np.asarray(trans_input, dtype=np.float64).reshape(6)
+        item["color"] = color
+        item["input_hw"] = np.array([input_h, input_w], dtype=np.int32)
+        if self.split != "train":
+            item["meta"] = {"c": c, "s": np.float32(s) if np.isscalar(s) else s, "img_id": img_id,
+                            "out_width": input_w, "out_height": input_h}
+        return item
+
+
+def build_inputs(image_u8, trans_input, color, mean, std, input_h, input_w):
+    """Device half of the sampler's image path: image_u8 [B,H,W,3] uint8 HIP tensor (already mirrored
+    where flipped), trans_input [B,6] / color [B,10] host arrays -> network input fp32 [B,3,h,w]."""
+    import ctypes
+
+    from ...utils.image import warp_affine_normalize
+    if not image_u8.is_cuda:
+        raise _C.NativeError("build_inputs needs HIP device tensors; there is no CPU fallback")
+    lib = _C.lib()
+    B = image_u8.shape[0]
+    out = torch.empty((B, 3, int(input_h), int(input_w)), dtype=torch.float32, device=image_u8.device)
+    nws = lib.cp_color_aug_workspace_bytes()
+    ws = _C.workspace(nws, image_u8.device)
+    m = (ctypes.c_float * 3)(*[float(v) for v in np.asarray(mean, np.float32).ravel()])
+    sd = (ctypes.c_float * 3)(*[float(v) for v in np.asarray(std, np.float32).ravel()])
+    P = lambda arr: ctypes.cast(arr, ctypes.c_void_p)
+    for b in range(B):
+        out[b] = warp_affine_normalize(image_u8[b], trans_input[b], (0.0, 0.0, 0.0), (1.0, 1.0, 1.0),
+                                       input_h, input_w)[0]
+        col = np.asarray(color[b], dtype=np.float64)
+        order = (ctypes.c_int32 * 3)(*[int(v) for v in col[1:4]])
+        alpha = (ctypes.c_float * 3)(*[float(np.float32(v)) for v in col[4:7]])
+        light = (ctypes.c_double * 3)(*[float(v) for v in col[7:10]])
+        _C.check(lib.cp_color_aug_normalize(_C.c_void_p(out[b].data_ptr()), int(input_h) * int(input_w),
+                                            1 if col[0] != 0 else 0, P(order), P(alpha), P(light), P(m), P(sd),
+                                            _C.ptr(ws), nws, _C.stream()), "cp_color_aug_normalize")
+    return out

@@ -14,7 +14,8 @@ class opts(object):
     def __init__(self):
         p = argparse.ArgumentParser()
         p.add_argument("task", default="polydet", nargs="?", help="polydet")
-        p.add_argument("--dataset", default="cityscapes")
+        p.add_argument("--dataset", default="cityscapes",
+                       help="cityscapes | kitti_poly | IDD (annotation JSON + images) | synthetic (offline)")
         p.add_argument("--exp_id", default="default")
         p.add_argument("--test", action="store_true")
         p.add_argument("--debug", type=int, default=0)
@@ -29,7 +30,7 @@ class opts(object):
         p.add_argument("--save_all", action="store_true")
         p.add_argument("--metric", default="loss")
         # model
-        p.add_argument("--arch", default="smallhourglass",
+        p.add_argument("--arch", default="dla_34",
                        help="dla_34 | hourglass | smallhourglass")
         p.add_argument("--head_conv", type=int, default=-1)
         p.add_argument("--down_ratio", type=int, default=4)
@@ -59,6 +60,15 @@ class opts(object):
                        help="loader workers only pack the raw annotations; heat maps and regression "
                             "targets are built on the GPU (cp_polydet_targets) after the batch upload")
         p.add_argument("--no_reorder_flip", action="store_true")
+        # sampler augmentation (reference: opts.py "train" group)
+        p.add_argument("--not_rand_crop", action="store_true")
+        p.add_argument("--shift", type=float, default=0.1)
+        p.add_argument("--scale", type=float, default=0.4)
+        p.add_argument("--flip", type=float, default=0.5)
+        p.add_argument("--no_color_aug", action="store_true")
+        p.add_argument("--annot_dir", default="",
+                       help="directory of the annotation JSON files (reference: ../<dataset>Stuff/BBoxes)")
+        p.add_argument("--img_dir", default="", help="directory of the image files")
         p.add_argument("--bucket_cap_mb", type=int, default=32,
                        help="gradient all-reduce bucket size (RCCL over xGMI)")
         # test

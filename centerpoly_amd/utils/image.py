@@ -89,3 +89,82 @@ def warp_affine_normalize(image_u8, trans, mean, std, dst_h, dst_w, flip_copy=Fa
         ctypes.cast(m, ctypes.c_void_p), ctypes.cast(sd, ctypes.c_void_p), int(dst_h), int(dst_w),
         1 if flip_copy else 0, _C.ptr(out), _C.stream()), "cp_preprocess_warp_normalize")
     return out
+
+
+# ---- host-side helpers of the reference's sampler, kept for API parity (src/lib/utils/image.py) ----
+# The accelerated path builds targets and augments inputs on the device (cp_polydet_targets,
+# cp_preprocess_warp_normalize, cp_color_aug_normalize); these numpy forms serve code that imports the
+# reference's names (`from utils.image import flip, color_aug, gaussian_radius, draw_umich_gaussian`).
+
+def flip(img):
+    """utils/image.py:16-17: mirror the last (width) axis of a CHW / NCHW array."""
+    return img[..., ::-1].copy()
+
+
+def gaussian_radius(det_size, min_overlap=0.7):
+    """utils/image.py:95-115: the smallest of the three radii for which a box displaced by r still
+    overlaps the ground truth with IoU >= min_overlap (the reference's literal quadratic roots,
+    `(b + sqrt(b^2 - 4ac)) / 2` without the division by a)."""
+    h, w = det_size
+    s, p, k = h + w, w * h, min_overlap
+    abc = ((1.0, s, p * (1 - k) / (1 + k)), (4.0, 2 * s, (1 - k) * p), (4 * k, -2 * k * s, (k - 1) * p))
+    return min((b + np.sqrt(b ** 2 - 4 * a * c)) / 2 for a, b, c in abc)
+
+
+def gaussian2D(shape, sigma=1):
+    """utils/image.py:118-124: un-normalised Gaussian window, entries below eps * max zeroed."""
+    ry, rx = [(n - 1.0) / 2.0 for n in shape]
+    yy, xx = np.ogrid[-ry:ry + 1, -rx:rx + 1]
+    g = np.exp(-(xx * xx + yy * yy) / (2 * sigma * sigma))
+    g[g < np.finfo(g.dtype).eps * g.max()] = 0
+    return g
+
+
+def draw_umich_gaussian(heatmap, center, radius, k=1):
+    """utils/image.py:126-141: max-composite a (2r+1)^2 Gaussian (sigma = (2r+1)/6) at an integer centre."""
+    d = 2 * radius + 1
+    g = gaussian2D((d, d), sigma=d / 6)
+    cx, cy = int(center[0]), int(center[1])
+    H, W = heatmap.shape[:2]
+    l, r = min(cx, radius), min(W - cx, radius + 1)
+    t, b = min(cy, radius), min(H - cy, radius + 1)
+    dst = heatmap[cy - t:cy + b, cx - l:cx + r]
+    src = g[radius - t:radius + b, radius - l:radius + r]
+    if min(src.shape) > 0 and min(dst.shape) > 0:
+        np.maximum(dst, src * k, out=dst)
+    return heatmap
+
+
+def grayscale(image):
+    """cv2.cvtColor(image, COLOR_BGR2GRAY) on a float BGR image: 0.114 B + 0.587 G + 0.299 R."""
+    return (image[..., 0] * np.float32(0.114) + image[..., 1] * np.float32(0.587)
+            + image[..., 2] * np.float32(0.299)).astype(image.dtype)
+
+
+def color_aug_params(data_rng, shuffle_rng=None):
+    """The random draws of color_aug (utils/image.py:255-264) without touching an image: the order of
+    brightness (0) / contrast (1) / saturation (2), their three alphas (1 + U(-0.4, 0.4), drawn in
+    application order) and the lighting alphas N(0, 0.1)^3.  The device kernel applies them."""
+    import random
+    order = [0, 1, 2]
+    (shuffle_rng or random).shuffle(order)
+    alphas = [1.0 + data_rng.uniform(low=-0.4, high=0.4) for _ in order]
+    light = data_rng.normal(scale=0.1, size=(3,))
+    return order, alphas, light
+
+
+def color_aug(data_rng, image, eig_val, eig_vec):
+    """utils/image.py:255-264 on a float BGR HWC image, in place (host form of cp_color_aug_normalize)."""
+    order, alphas, light = color_aug_params(data_rng)
+    gs = grayscale(image)
+    gs_mean = gs.mean()
+    for op, alpha in zip(order, alphas):
+        if op == 0:                                   # brightness_
+            image *= alpha
+        elif op == 1:                                 # contrast_: blend with the mean grey level
+            image *= alpha
+            image += gs_mean * (1 - alpha)
+        else:                                         # saturation_: blend with the grey image
+            image *= alpha
+            image += gs[:, :, None] * (1 - alpha)
+    image += np.dot(eig_vec, eig_val * light)         # lighting_

@@ -184,6 +184,19 @@ int cp_preprocess_warp_normalize(const uint8_t* src, int32_t src_h, int32_t src_
                                  const double* trans, const float* mean, const float* stdv,
                                  int32_t dst_h, int32_t dst_w, int32_t flip_copy, float* out,
                                  void* stream);
+
+/* cp_color_aug_normalize: the colour augmentation + normalisation of the TRAINING sampler
+ * (src/lib/datasets/sample/polydet.py:128-136: `inp / 255.` -> color_aug -> `(inp - mean) / std`;
+ * src/lib/utils/image.py:231-264) in place on the warped input, BGR planes [3][HW] holding x / 255
+ * (cp_preprocess_warp_normalize with mean 0 / std 1).  The random draws stay with the caller
+ * (reference: data_rng + random.shuffle in the loader worker): order[3] = the three ops in
+ * application order (0 brightness, 1 contrast, 2 saturation), alpha[3] their blend factors,
+ * light[3] = eig_vec . (eig_val * alpha_pca) per BGR channel (float64).  color_on == 0 only
+ * normalises.  All HOST pointers except img / workspace (cp_color_aug_workspace_bytes). */
+size_t cp_color_aug_workspace_bytes(void);
+int cp_color_aug_normalize(float* img, int64_t HW, int32_t color_on, const int32_t* order,
+                           const float* alpha, const double* light, const float* mean, const float* stdv,
+                           void* workspace, size_t workspace_bytes, void* stream);
 int cp_polydet_post_process(const float* dets, const double* trans_dev, float scale, int32_t B,
                             int32_t K, int32_t ncols, float* out, void* stream);
 

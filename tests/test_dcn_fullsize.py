@@ -1,0 +1,207 @@
+"""DCNv2 backward at the launch shapes the training bench times (BASELINE configs 3 and 5), where the
+CPU oracle is too slow to run whole: oracle-free identities at full size plus an oracle comparison on
+a band cropped from the full problem.
+
+  adjoint      <g, L x> = <L^T g, x> for the maps x -> y and W -> y (y is linear in both for fixed
+               offsets / mask): ties grad_x and grad_weight of cp_dcn_v2_backward to
+               cp_dcn_v2_forward, which is itself checked against the oracle
+  linearity    bwd(g1 + g2) = bwd(g1) + bwd(g2); bwd(2 g) = 2 bwd(g) bit for bit
+  batch split  the B-image launch equals B single-image launches
+  determinism  grad_x / grad_offset / grad_mask bit-equal between two runs (fixed-point region sums,
+               slab reduction in a fixed order; the cold path's float atomics are excluded by keeping
+               the offsets inside the LDS region)
+  band         grad_x / grad_offset / grad_mask of a 48-row x 96-column window of the full problem
+               against torch autograd through oracle/dcn.py on that window (+ margin)
+
+Reference semantics: upstream dcn_v2_backward as restated in oracle/dcn.py (call site
+src/lib/models/networks/pose_dla_dcn.py:354)."""
+import numpy as np
+import pytest
+import torch
+
+from centerpoly_amd import _C, synth
+from oracle import dcn as odcn
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+# (B, Cin, Cout, H, W): config 3's dominant launches and the KITTI shape of config 5
+FULL_SHAPES = [(4, 64, 64, 256, 512), (4, 128, 64, 128, 256), (4, 128, 128, 128, 256), (4, 256, 256, 64, 128),
+               (4, 512, 256, 32, 64), (8, 64, 64, 96, 320)]
+IDS = ["x".join(map(str, s)) for s in FULL_SHAPES]
+
+
+def _inputs(tag, B, Cin, Cout, H, W, off_std=0.5, clip=None):
+    x = torch.from_numpy(synth.normal("full/%s/x" % tag, (B, Cin, H, W))).to(DEV)
+    om = synth.normal("full/%s/om" % tag, (B, 27, H, W))
+    om[:, :18] *= off_std
+    if clip is not None:
+        om[:, :18] = np.clip(om[:, :18], -clip, clip)
+    om = torch.from_numpy(om).to(DEV)
+    w = torch.from_numpy(synth.normal("full/%s/w" % tag, (Cout, Cin, 3, 3), 0.0, 1.0 / np.sqrt(Cin * 9))).to(DEV)
+    go = torch.from_numpy(synth.normal("full/%s/go" % tag, (B, Cout, H, W))).to(DEV)
+    return x, om, w, go
+
+
+def _backward(x, om, w, go, want=("x", "om", "w", "b")):
+    """cp_dcn_v2_backward through the C ABI on the raw 27-channel offset/mask tensor (mask as logits)."""
+    L = _C.lib()
+    B, Cin, H, W = x.shape
+    Cout = w.shape[0]
+    s = _C.DcnShape(B, Cin, H, W, Cout, 3, 3, 1, 1, 1, 1)
+    gx = torch.zeros_like(x) if "x" in want else None
+    gom = torch.full_like(om, float("nan")) if "om" in want else None      # must be fully overwritten
+    gw = torch.zeros_like(w) if "w" in want else None
+    gb = torch.zeros(Cout, device=DEV) if "b" in want else None
+    bs = 27 * H * W
+    off_m = 4 * 18 * H * W
+    nws = L.cp_dcn_v2_backward_workspace_bytes(s)
+    ws = _C.workspace(nws, x.device)
+    rc = L.cp_dcn_v2_backward(s, _C.ptr(x), _C.ptr(om), bs, _C.c_void_p(om.data_ptr() + off_m), bs, 1, _C.ptr(w),
+                              _C.ptr(go), _C.ptr(gx), _C.ptr(gom), bs,
+                              _C.c_void_p(gom.data_ptr() + off_m) if gom is not None else None, bs, _C.ptr(gw),
+                              _C.ptr(gb), _C.ptr(ws), nws, _C.stream())
+    _C.check(rc, "cp_dcn_v2_backward")
+    torch.cuda.synchronize()
+    return gx, gom, gw, gb
+
+
+def _dot(a, b):
+    return (a.double() * b.double()).sum().item()
+
+
+@pytest.mark.parametrize("shape", FULL_SHAPES, ids=IDS)
+def test_adjoint_identity_full_size(shape):
+    from centerpoly_amd.models.networks.DCNv2.dcn_v2 import dcn_v2_forward_raw
+    x, om, w, go = _inputs("adj", *shape)
+    zero_b = torch.zeros(shape[2], device=DEV)
+    y = dcn_v2_forward_raw(x, om, w, zero_b)
+    gx, gom, gw, gb = _backward(x, om, w, go)
+    lhs = _dot(go, y)
+    norm = (go.double().square().sum().sqrt() * y.double().square().sum().sqrt()).item()
+    # <g, L x> = <L^T g, x>  and  <g, y(W)> = <grad_W, W>: both sides are sums of ~1e8 products; the
+    # tolerance is relative to |g| |y| (fp32 accumulation inside the kernels, float64 dots here)
+    assert abs(lhs - _dot(gx, x)) <= 2e-6 * norm, (lhs, _dot(gx, x), norm)
+    assert abs(lhs - _dot(gw, w)) <= 2e-6 * norm, (lhs, _dot(gw, w), norm)
+    ref_b = go.double().sum(dim=(0, 2, 3))
+    np.testing.assert_allclose(gb.double().cpu().numpy(), ref_b.cpu().numpy(), rtol=1e-4,
+                               atol=1e-5 * ref_b.abs().max().item())
+    assert torch.isfinite(gom).all()                     # every offset / mask gradient was written
+
+
+@pytest.mark.parametrize("shape", [FULL_SHAPES[0], FULL_SHAPES[3], FULL_SHAPES[5]],
+                         ids=[IDS[0], IDS[3], IDS[5]])
+def test_linearity_in_grad_out_full_size(shape):
+    x, om, w, g1 = _inputs("lin", *shape, clip=1.9)
+    g2 = torch.from_numpy(synth.normal("full/lin/go2", tuple(g1.shape))).to(DEV)
+    r1 = _backward(x, om, w, g1)
+    r2 = _backward(x, om, w, g2)
+    r12 = _backward(x, om, w, g1 + g2)
+    rd = _backward(x, om, w, 2.0 * g1)
+    for name, a, b, c, d in zip(("x", "om", "w", "b"), r1, r2, r12, rd):
+        scale = c.abs().max().item()
+        assert (a + b - c).abs().max().item() <= 2e-5 * scale, name
+        if name in ("x", "om"):          # power-of-two scaling commutes with every rounding on this path
+            assert torch.equal(d, 2.0 * a), name
+        else:                            # float-atomic flush of the weight / bias kernels: order varies
+            assert (d - 2.0 * a).abs().max().item() <= 1e-5 * scale, name
+
+
+@pytest.mark.parametrize("shape", [FULL_SHAPES[0], FULL_SHAPES[2]], ids=[IDS[0], IDS[2]])
+def test_batch_split_equality_and_determinism_full_size(shape):
+    B = shape[0]
+    x, om, w, go = _inputs("split", *shape, clip=1.9)     # every tap stays inside the LDS region
+    gx, gom, gw, gb = _backward(x, om, w, go)
+    gx2, gom2, _, _ = _backward(x, om, w, go, want=("x", "om"))
+    assert torch.equal(gx, gx2) and torch.equal(gom, gom2), "data gradients differ between two runs"
+    gw_sum = torch.zeros_like(gw)
+    for b in range(B):
+        sx, som, sw, _ = _backward(x[b:b + 1].contiguous(), om[b:b + 1].contiguous(), w, go[b:b + 1].contiguous())
+        assert torch.equal(sx[0], gx[b]), "grad_x of image %d depends on the batch" % b
+        # a one-image launch may split the input channels over more workgroups than the batched one
+        # (grid filling): its grad_offset / grad_mask partial sums then meet in another order
+        assert (som[0] - gom[b]).abs().max().item() <= 1e-5 * gom[b].abs().max().item(), \
+            "grad_offset/mask of image %d depends on the batch" % b
+        gw_sum += sw
+    assert (gw_sum - gw).abs().max().item() <= 2e-5 * gw.abs().max().item()
+
+
+@pytest.mark.parametrize("shape,off_std", [(FULL_SHAPES[0], 0.5), (FULL_SHAPES[0], 2.0), (FULL_SHAPES[2], 0.5),
+                                           (FULL_SHAPES[5], 1.0)],
+                         ids=["%s-off%.1f" % (IDS[i], o) for i, o in ((0, 0.5), (0, 2.0), (2, 0.5), (5, 1.0))])
+def test_band_of_the_full_problem_vs_oracle(shape, off_std):
+    """Crop a window (+ margin) out of the full tensors, run torch autograd through the oracle on the
+    crop, and compare the window's data gradients with the full-size HIP launch.  Offsets are clipped
+    to the margin so the window's gradients do not see the crop's border."""
+    B, Cin, Cout, H, W = shape
+    margin, hh, ww = 8, min(48, H - 16), min(96, W - 16)
+    x, om, w, go = _inputs("band", *shape, off_std=off_std, clip=margin - 3.0)
+    gx, gom, _, _ = _backward(x, om, w, go, want=("x", "om"))
+    b = B - 1
+    r0 = int(synth.integers("full/band/r0", (1,), margin, H - hh - margin + 1)[0])
+    c0 = int(synth.integers("full/band/c0", (1,), margin, W - ww - margin + 1)[0])
+    rs, cs = slice(r0 - margin, r0 + hh + margin), slice(c0 - margin, c0 + ww + margin)
+    tx = x[b:b + 1, :, rs, cs].cpu().requires_grad_(True)
+    tom = om[b:b + 1, :, rs, cs].cpu().requires_grad_(True)
+    tgo = go[b:b + 1, :, rs, cs].cpu()
+    o1, o2, m = torch.chunk(tom, 3, dim=1)
+    ref = odcn.dcn_v2_forward(tx, torch.cat((o1, o2), 1), torch.sigmoid(m), w.cpu(), None)
+    ref.backward(tgo)
+    inner = (slice(None), slice(margin, margin + hh), slice(margin, margin + ww))
+    want_om = tom.grad[0][inner].numpy()
+    got_om = gom[b][:, r0:r0 + hh, c0:c0 + ww].cpu().numpy()
+    # d/d(offset) jumps where the sampling coordinate crosses an integer (kink of the bilinear
+    # interpolant), and `row + offset` rounds differently in the crop's frame than in the full image's:
+    # offset gradients within 1e-3 px of a kink are not compared (both values are one-sided limits)
+    om_w = om[b][:18, r0:r0 + hh, c0:c0 + ww].cpu().numpy().astype(np.float64)
+    frac = om_w - np.floor(om_w)
+    kink = np.zeros(got_om.shape, bool)
+    kink[:18] = (frac < 1e-3) | (frac > 1 - 1e-3)
+    assert kink.mean() < 0.03
+    np.testing.assert_allclose(np.where(kink, 0, got_om), np.where(kink, 0, want_om), rtol=1e-3,
+                               atol=2e-5 * np.abs(want_om).max(), err_msg="grad_offset / grad_mask")
+    # a grad_x element receives contributions from grad_out pixels at most (offset clip + 2) = margin - 1
+    # away and a grad_offset element reads x that close: the crop (window + margin) holds all of them
+    want_x = tx.grad[0][inner]
+    got_x = gx[b][:, r0:r0 + hh, c0:c0 + ww].cpu()
+    np.testing.assert_allclose(got_x.numpy(), want_x.numpy(), rtol=1e-3, atol=2e-5 * want_x.abs().max().item(),
+                               err_msg="grad_x")
+
+
+def test_focal_and_bn_act_at_training_size():
+    """Fused sigmoid+focal forward/backward and BN+ReLU at the B=4 training shape against torch fp32."""
+    from centerpoly_amd.models.losses import sigmoid_focal_loss
+    B, C, H, W = 4, 8, 256, 512
+    logits = torch.from_numpy(synth.heat_logits("full/focal", B, C, H, W)).to(DEV)
+    nb = synth.train_batch(B, H, W, nbr_points=16, rep="cartesian", stream="full/focal/batch", in_h=4 * H, in_w=4 * W)
+    gt = torch.from_numpy(nb["hm"]).to(DEV)
+    a = logits.clone().requires_grad_(True)
+    loss, _ = sigmoid_focal_loss(a * 1.0, gt)            # the kernel activates its input in place
+    loss.backward()
+    r = logits.clone().requires_grad_(True)
+    p = torch.clamp(torch.sigmoid(r), 1e-4, 1 - 1e-4)
+    pos = gt.eq(1).float()
+    neg = gt.lt(1).float()
+    pl = (torch.log(p) * (1 - p) ** 2 * pos).double().sum()
+    nl = (torch.log(1 - p) * p ** 2 * (1 - gt) ** 4 * neg).double().sum()
+    ref = -(pl + nl) / pos.sum().double()
+    ref.backward()
+    assert abs(loss.item() - ref.item()) <= 1e-5 * abs(ref.item())
+    scale = r.grad.abs().max().item()
+    assert (a.grad - r.grad).abs().max().item() <= 1e-4 * scale
+    from centerpoly_amd.models.networks.pose_dla_dcn import bn_act
+    bn = torch.nn.BatchNorm2d(64).to(DEV).train()
+    x = torch.from_numpy(synth.normal("full/bn/x", (4, 64, 256, 512))).to(DEV)
+    go = torch.from_numpy(synth.normal("full/bn/go", (4, 64, 256, 512))).to(DEV)
+    x1 = x.clone().requires_grad_(True)
+    y1 = bn_act(bn, x1, relu=True)
+    y1.backward(go)
+    g1 = (x1.grad.clone(), bn.weight.grad.clone(), bn.bias.grad.clone())
+    bn.zero_grad()
+    bn2 = torch.nn.BatchNorm2d(64).to(DEV).train()
+    x2 = x.clone().requires_grad_(True)
+    y2 = torch.relu(bn2(x2))
+    y2.backward(go)
+    torch.testing.assert_close(y1, y2, rtol=1e-4, atol=1e-5)
+    for u, v in zip(g1, (x2.grad, bn2.weight.grad, bn2.bias.grad)):
+        assert (u - v).abs().max().item() <= 1e-4 * v.abs().max().item()

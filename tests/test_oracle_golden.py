@@ -175,3 +175,49 @@ def test_post_process_matches_reference(golden):
     for j in range(1, C + 1):
         a = np.array(ret[0][j], dtype=np.float32).reshape(-1, 2 * N + 6)
         np.testing.assert_allclose(a, g["cls%d" % j], rtol=1e-6, atol=1e-4)
+
+
+# ---- DCNv2: two independently structured derivations held against each other -------------------
+@pytest.mark.parametrize("case", [(1, 3, 4, 6, 7, 0.7, 1), (2, 2, 3, 5, 5, 3.0, 1), (1, 2, 2, 4, 9, 8.0, 1),
+                                  (1, 3, 2, 7, 6, 1.5, 2)],
+                         ids=["small-offsets", "3px-offsets", "samples-leave-the-image", "dilation-2"])
+def test_dcn_definition_vs_upstream_kernel_rules(case):
+    """oracle/dcn.py (definition + torch autograd, float64 here) against oracle/dcn_im2col.py (the
+    published im2col / col2im / col2im_coord kernels' own formulas, no autograd): forward and all
+    five gradients.  Neither is pinned by the reference (DCNv2 is absent from it); this pins them to
+    each other."""
+    import torch
+    from centerpoly_amd import synth
+    from oracle import dcn as odcn
+    from oracle import dcn_im2col as oim
+    B, Cin, Cout, H, W, off_std, dil = case
+    tag = "dcn2/%d%d%d%d%d" % (B, Cin, Cout, H, W)
+    x = synth.normal(tag + "/x", (B, Cin, H, W)).astype(np.float64)
+    off = synth.normal(tag + "/off", (B, 18, H, W)).astype(np.float64) * off_std + 0.013
+    msk = 1.0 / (1.0 + np.exp(-synth.normal(tag + "/m", (B, 9, H, W)).astype(np.float64)))
+    w = synth.normal(tag + "/w", (Cout, Cin, 3, 3)).astype(np.float64)
+    b = synth.normal(tag + "/b", (Cout,)).astype(np.float64)
+    go = synth.normal(tag + "/go", (B, Cout, H, W)).astype(np.float64)
+    tx, toff, tm, tw, tb = (torch.from_numpy(v).requires_grad_(True) for v in (x, off, msk, w, b))
+    y = odcn.dcn_v2_forward(tx, toff, tm, tw, tb, 1, dil, dil)
+    y.backward(torch.from_numpy(go))
+    y2 = oim.forward(x, off, msk, w, b, 1, dil, dil)
+    np.testing.assert_allclose(y2, y.detach().numpy(), rtol=1e-10, atol=1e-10)
+    gi, goff, gm, gw, gb = oim.backward(x, off, msk, w, go, 1, dil, dil)
+    for name, got, want in (("input", gi, tx.grad), ("offset", goff, toff.grad), ("mask", gm, tm.grad),
+                            ("weight", gw, tw.grad), ("bias", gb, tb.grad)):
+        np.testing.assert_allclose(got, want.numpy(), rtol=1e-9, atol=1e-9, err_msg="grad_" + name)
+
+
+def test_dcn_zero_offset_known_answer_im2col():
+    """Known answer for the kernel-rule restatement: zero offsets and mask 0.5 give 0.5*conv2d + b."""
+    import torch
+    from centerpoly_amd import synth
+    from oracle import dcn_im2col as oim
+    x = synth.normal("dcn2/kat/x", (1, 3, 6, 5)).astype(np.float64)
+    w = synth.normal("dcn2/kat/w", (4, 3, 3, 3)).astype(np.float64)
+    b = synth.normal("dcn2/kat/b", (4,)).astype(np.float64)
+    y = oim.forward(x, np.zeros((1, 18, 6, 5)), np.full((1, 9, 6, 5), 0.5), w, b)
+    ref = 0.5 * torch.nn.functional.conv2d(torch.from_numpy(x), torch.from_numpy(w), None, padding=1) \
+        + torch.from_numpy(b).view(1, -1, 1, 1)
+    np.testing.assert_allclose(y, ref.numpy(), rtol=1e-12, atol=1e-12)

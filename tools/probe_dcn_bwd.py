@@ -9,7 +9,7 @@ L = _C.lib()
 dev = "cuda"
 
 
-def run(B, ci, co, H, W, what, n=20, off_scale=0.5):
+def run(B, ci, co, H, W, what, n=20, off_scale=float(os.environ.get("PROBE_OFF_STD", "0.5"))):
     x = torch.from_numpy(synth.normal("pb/x", (B, ci, H, W))).to(dev)
     om = torch.from_numpy(synth.normal("pb/om", (B, 27, H, W)) * off_scale).to(dev)
     w = torch.from_numpy(synth.normal("pb/w", (co, ci, 3, 3), 0, 0.05)).to(dev)
@@ -19,12 +19,14 @@ def run(B, ci, co, H, W, what, n=20, off_scale=0.5):
     bs = 27 * H * W; off_m = 72 * H * W
     P = lambda t: ctypes.c_void_p(t.data_ptr())
     data, weight = what != "weight", what != "data"
+    nws = L.cp_dcn_v2_backward_workspace_bytes(s)
+    ws = _C.workspace(nws, dev)
 
     def call():
         rc = L.cp_dcn_v2_backward(s, P(x), P(om), bs, ctypes.c_void_p(om.data_ptr() + off_m), bs, 1, P(w), P(go),
                                   P(gx) if data else None, P(gom) if data else None, bs,
                                   ctypes.c_void_p(gom.data_ptr() + off_m) if data else None, bs,
-                                  P(gw) if weight else None, None, None, 0, _C.stream())
+                                  P(gw) if weight else None, None, P(ws), nws, _C.stream())
         assert rc == 0, rc
     for _ in range(5):
         call()
