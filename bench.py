@@ -438,7 +438,7 @@ def physical_cores():
     n = max(1, len(cores))
     if quota is not None:
         n = max(1, min(n, int(quota + 0.5)))
-    n = min(n, int(os.environ.get("CP_CPU_BASELINE_THREADS", "32")))     # bound: the oracle stops scaling past ~32 threads
+    n = min(n, int(os.environ.get("CP_CPU_BASELINE_THREADS", "32")))     # bound: the CPU port stops scaling past ~32 threads
     return n, len(cpus), quota
 
 

@@ -855,7 +855,9 @@ extern "C" int cp_dcn_v2_forward(const cp_dcn_shape* s, const float* x, const fl
     if (p.bn == 64) return launch_bf16x3<64, 2>(a, st);
     return launch_bf16x3<128, 1>(a, st);
   }
-  if (!getenv("CP_DCN_PHASED")) {                 // interleaved kernel (default)
+  // A/B switch for timing runs (phase-separated kernel); read once per process, never on the call path
+  static const bool phased = getenv("CP_DCN_PHASED") != nullptr;
+  if (!phased) {                                  // interleaved kernel (default)
     if (p.bn == 64) return launch_pipe<64, 3>(a, st);
     if (p.bn == 128) return launch_pipe<128, 2>(a, st);
   }

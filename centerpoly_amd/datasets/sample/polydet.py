@@ -9,6 +9,7 @@ the GPU `build_targets` turns them into the batch dict of :425-449 with two HIP 
 """
 import numpy as np
 import torch
+import torch.utils.data
 
 from ... import _C
 
@@ -84,7 +85,7 @@ def build_targets(raw, output_h, output_w, num_classes, rep="cartesian", no_reor
     return out
 
 
-class PolydetDataset(object):
+class PolydetDataset(torch.utils.data.Dataset):
     """Sampler mixed into a dataset class by get_dataset (reference: PolydetDataset.__getitem__,
     src/lib/datasets/sample/polydet.py:66-449), split between host and device:
 

@@ -10,6 +10,21 @@ import argparse
 import os
 
 
+def chunk_sizes_for(batch_size, master_batch_size, n):
+    """Per-replica share of a global batch (reference: src/lib/opts.py:301-310): replica 0 takes
+    `master_batch_size` (default batch_size // n), the rest is spread over the others, the first ones
+    taking the remainder."""
+    master = batch_size // n if master_batch_size == -1 else master_batch_size
+    rest = batch_size - master
+    sizes = [master]
+    for i in range(n - 1):
+        chunk = rest // (n - 1)
+        if i < rest % (n - 1):
+            chunk += 1
+        sizes.append(chunk)
+    return sizes
+
+
 class opts(object):
     def __init__(self):
         p = argparse.ArgumentParser()
@@ -113,15 +128,9 @@ class opts(object):
         opt.num_stacks = 2 if opt.arch == "hourglass" else 1
         if opt.trainval:
             opt.val_intervals = 100000000
-        if opt.master_batch_size == -1:
-            opt.master_batch_size = opt.batch_size // len(opt.gpus)
-        rest = opt.batch_size - opt.master_batch_size
-        opt.chunk_sizes = [opt.master_batch_size]
-        for i in range(len(opt.gpus) - 1):
-            chunk = rest // (len(opt.gpus) - 1)
-            if i < rest % (len(opt.gpus) - 1):
-                chunk += 1
-            opt.chunk_sizes.append(chunk)
+        opt.master_batch_size_arg = opt.master_batch_size
+        opt.chunk_sizes = chunk_sizes_for(opt.batch_size, opt.master_batch_size, len(opt.gpus))
+        opt.master_batch_size = opt.chunk_sizes[0]
         opt.root_dir = os.path.join(opt.root_dir)
         opt.data_dir = opt.root_dir
         opt.exp_dir = os.path.join(opt.root_dir, "exp", opt.dataset, opt.task)

@@ -86,8 +86,14 @@ class PolydetTrainer(BaseTrainer):
         object in the sampler, src/lib/datasets/sample/polydet.py:160-405)."""
         if "trans_output" not in batch:
             return batch
-        from ..datasets.sample.polydet import build_targets
+        from ..datasets.sample.polydet import build_inputs, build_targets
         opt = self.opt
+        if "image_u8" in batch:
+            # real datasets: the loader delivered 8-bit images + the drawn augmentation; warp, colour
+            # augmentation and normalisation run here (sample/polydet.py:106-136 of the reference)
+            hw = batch["input_hw"][0].tolist()
+            batch["input"] = build_inputs(batch["image_u8"], batch["trans_input"].cpu().numpy(),
+                                          batch["color"].cpu().numpy(), opt.mean, opt.std, hw[0], hw[1])
         h, w = batch["input"].shape[2] // opt.down_ratio, batch["input"].shape[3] // opt.down_ratio
         targets = build_targets(batch, h, w, opt.num_classes, rep=opt.rep,
                                 no_reorder_flip=getattr(opt, "no_reorder_flip", False),

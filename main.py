@@ -46,6 +46,11 @@ def main(opt):
     trainer.set_device(opt.gpus, opt.chunk_sizes, opt.device)
 
     per_rank = max(1, opt.batch_size // world)
+    if world > 1 and len(opt.chunk_sizes) != world:
+        # opts derives chunk_sizes from --gpus (reference: opts.py:301-310); under torchrun the rank
+        # count is the world size
+        from centerpoly_amd.opts import chunk_sizes_for
+        opt.chunk_sizes = chunk_sizes_for(opt.batch_size, opt.master_batch_size_arg, world)
     val_loader = torch.utils.data.DataLoader(Dataset(opt, "val"), batch_size=1, shuffle=False,
                                              num_workers=1, pin_memory=False)
     if opt.test:
@@ -53,14 +58,21 @@ def main(opt):
         val_loader.dataset.run_eval(preds, opt.save_dir)
         return
     train_set = Dataset(opt, "train")
-    sampler = torch.utils.data.distributed.DistributedSampler(train_set) if world > 1 else None
-    train_loader = torch.utils.data.DataLoader(train_set, batch_size=per_rank, shuffle=sampler is None,
-                                               sampler=sampler, num_workers=opt.num_workers,
-                                               # pageable batches: 100 MB reach the GPU in 1.9 ms, while host
-                                               # writes into pinned staging memory followed by non-blocking
-                                               # copies showed periodic ~90 ms stalls on MI355X
-                                               # (tools/probe_stalls.py); the reference pins (main.py:59)
-                                               pin_memory=False, drop_last=True)
+    sampler = None
+    loader_kw = dict(num_workers=opt.num_workers,
+                     # pageable batches: 100 MB reach the GPU in 1.9 ms, while host writes into pinned
+                     # staging memory followed by non-blocking copies showed periodic ~90 ms stalls on
+                     # MI355X (tools/probe_stalls.py); the reference pins (main.py:59)
+                     pin_memory=False)
+    if world > 1:
+        # rank r takes chunk_sizes[r] samples of every global batch (even split unless
+        # --master_batch_size says otherwise), no data collective
+        from centerpoly_amd.utils.sampler import ChunkedDistributedSampler
+        sampler = ChunkedDistributedSampler(len(train_set), opt.chunk_sizes, rank, shuffle=True, seed=opt.seed)
+        train_loader = torch.utils.data.DataLoader(train_set, batch_sampler=sampler, **loader_kw)
+    else:
+        train_loader = torch.utils.data.DataLoader(train_set, batch_size=per_rank, shuffle=True, drop_last=True,
+                                                   **loader_kw)
     if rank == 0:
         os.makedirs(opt.save_dir, exist_ok=True)
     print("Starting training...")

@@ -109,3 +109,27 @@ def pre_process(image, scale, mean, std, fix_res=False, input_h=None, input_w=No
     meta = {"c": c, "s": s, "out_height": inp_height // down_ratio,
             "out_width": inp_width // down_ratio}
     return images, meta, trans_input
+
+
+def color_aug_normalize(inp01, order, alphas, light_delta, mean, std, color_on=True):
+    """Colour augmentation + normalisation of the training sampler on a float32 BGR HWC image holding
+    x / 255 (src/lib/datasets/sample/polydet.py:128-136 -> src/lib/utils/image.py:231-264), with the random
+    draws passed in: `order` = the three ops in application order (0 brightness, 1 contrast, 2 saturation),
+    `alphas` their factors, `light_delta` = eig_vec . (eig_val * alpha_pca) (float64[3]).  numpy float32
+    arithmetic in the reference's order; cv2.cvtColor(BGR2GRAY) is restated as 0.114 B + 0.587 G + 0.299 R in
+    float32 (OpenCV itself is absent: unpinned, as the warp above).  Returns float32 CHW."""
+    img = np.array(inp01, dtype=np.float32, copy=True)
+    if color_on:
+        gs = (img[..., 0] * np.float32(0.114) + img[..., 1] * np.float32(0.587)) + img[..., 2] * np.float32(0.299)
+        gs = gs.astype(np.float32)
+        gs_mean = np.float32(np.float64(gs.astype(np.float64).sum()) / gs.size)
+        for op, alpha in zip(order, alphas):
+            a = np.float32(alpha)
+            img *= a
+            if op == 1:
+                img += gs_mean * (np.float32(1.0) - a)
+            elif op == 2:
+                img += (gs * (np.float32(1.0) - a))[:, :, None]
+        img = (img.astype(np.float64) + np.asarray(light_delta, np.float64).reshape(1, 1, 3)).astype(np.float32)
+    out = (img - np.asarray(mean, np.float32).reshape(1, 1, 3)) / np.asarray(std, np.float32).reshape(1, 1, 3)
+    return np.ascontiguousarray(out.transpose(2, 0, 1))
