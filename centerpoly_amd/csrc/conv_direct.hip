@@ -1,0 +1,231 @@
+// Direct convolution of the full-resolution, low-channel layers of the DLA base for gfx950, with the
+// folded-BatchNorm shift and the ReLU in the epilogue.
+//
+// Replaces, at inference, `base.base_layer` (7x7, 3 -> 16), `base.level0` (3x3, 16 -> 16) and
+// `base.level1` (3x3 stride 2, 16 -> 32) of the reference's DLA-34
+// (src/lib/models/networks/pose_dla_dcn.py:236-246,266-276): Conv2d(bias=False) -> BatchNorm2d ->
+// ReLU.  The library ran them as Winograd / implicit-GEMM kernels plus a separate bias+ReLU pass:
+// 371 + 240 + 112 us and 123 us of epilogues per 2048x1024 image (profiles/r01_infer_*), for layers
+// whose 16 channels make the work a thin contraction (K = 147 / 144) over 2 M pixels.
+//
+// Implicit GEMM on the f32 matrix instruction, out[co][px] = sum_k W[co][k] * x_patch[k][px]:
+//   A (weights, BN scale folded in): the wave's registers for the whole kernel -- lane (co = lane & 15,
+//     k = 4 ks + (lane >> 4)) holds one value per k-step (36..39 k-steps, x2 for 32 output channels);
+//   B (input patch): read per k-step from an LDS-staged halo tile, lane = (pixel lane & 15, k lane >> 4);
+//     k-order = tap-major for the 16-channel layers (a k-step = 4 input channels of one tap, so the
+//     four lane groups read the same tile position in four planes whose stride is 16 (stride 1) or 17
+//     (stride 2) banks: conflict-free), channel-major for the stem (a k-step = 4 taps of one channel,
+//     per-lane tap offsets precomputed, 49 taps padded to 52);
+//   D: pixel on the lane (16 consecutive pixels of a row), four output channels in the accumulator
+//     registers: bias + ReLU and 64-byte row-segment stores, no transposition.
+// One workgroup = 4 waves = an 8 x 64 (stride 1) or 4 x 64 (stride 2) output tile; the halo tile is
+// staged once with coalesced row loads.  Exact fp32 (fma chain of the MFMA), k-order differs from the
+// library's, so results agree with F.conv2d to rounding (tests: 1e-5 relative).
+#include "cp_common.h"
+
+namespace {
+
+constexpr unsigned OOBC = 0x80000000u;
+
+struct ConvArgs {
+  const float* x;
+  const float* w;       // [Cout][Cin][k][k], scale folded in by the caller
+  const float* bias;    // [Cout] or null
+  float* out;
+  int B, H, W, Ho, Wo;
+  int relu;
+};
+
+// ---------------------------------------------------------------- 3x3, 16 input channels ---
+template <int COUT, int STRIDE>
+__global__ __launch_bounds__(256) void conv3x3_c16_kernel(ConvArgs a) {
+  constexpr int CIN = 16, MT = COUT / 16, KS = 9 * CIN / 4;          // 36 k-steps
+  constexpr int TH = STRIDE == 1 ? 8 : 4, TW = 64;                   // output tile
+  constexpr int IH = (TH - 1) * STRIDE + 3, IW = (TW - 1) * STRIDE + 3;
+  constexpr int PITCH = STRIDE == 1 ? 72 : 137;                      // plane = IH * PITCH = 16 / 17 (mod 32)
+  constexpr int PLANE = IH * PITCH;
+  static_assert(PITCH >= IW, "pitch");
+  static_assert((PLANE % 32) == (STRIDE == 1 ? 16 : 17), "bank phase of the channel planes");
+  __shared__ float xs[CIN * PLANE];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lpx = lane & 15, g = lane >> 4;
+  const int b = blockIdx.z;
+  const int oy0 = blockIdx.y * TH, ox0 = blockIdx.x * TW;
+  const int iy0 = oy0 * STRIDE - 1, ix0 = ox0 * STRIDE - 1;
+  const int HW = a.H * a.W;
+
+  // weights -> registers: A[co = 16 m + lpx][k = 4 ks + g], k = tap * 16 + ci
+  float wa[MT][KS];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int k = 4 * ks + g, tap = k >> 4, ci = k & 15;
+      wa[m][ks] = a.w[((16 * m + lpx) * CIN + ci) * 9 + tap];
+    }
+
+  // stage the halo tile: coalesced rows, zero outside the image
+  const float* xb = a.x + (long long)b * CIN * HW;
+  const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(xb), 0, (int)((unsigned)CIN * (unsigned)HW * 4u), 0x00020000);
+  for (int e = tid; e < CIN * IH * IW; e += 256) {
+    const int ci = e / (IH * IW), r = e - ci * (IH * IW);
+    const int ry = r / IW, rx = r - ry * IW;
+    const int gy = iy0 + ry, gx = ix0 + rx;
+    const bool ok = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+    const unsigned off = ok ? ((unsigned)ci * (unsigned)HW + (unsigned)(gy * a.W + gx)) * 4u : OOBC;
+    xs[ci * PLANE + ry * PITCH + rx] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_x, off, 0, 0));
+  }
+  __syncthreads();
+
+  // wave w: rows [w * TH / 4, ...) of the tile, all four 16-pixel column tiles
+  constexpr int RPW = TH / 4 > 0 ? TH / 4 : 1;                       // rows per wave (2 or 1)
+  float bias_r[MT][4];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) bias_r[m][q] = a.bias ? a.bias[16 * m + 4 * g + q] : 0.f;
+  float* ob = a.out + (long long)b * COUT * a.Ho * a.Wo;
+#pragma unroll 1
+  for (int rr = 0; rr < RPW; ++rr) {
+    const int ty = wid * RPW + rr;
+#pragma unroll 1
+    for (int tx = 0; tx < TW / 16; ++tx) {
+      f32x4 acc[MT];
+#pragma unroll
+      for (int m = 0; m < MT; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const float* base = xs + g * PLANE + (ty * STRIDE) * PITCH + (tx * 16 + lpx) * STRIDE;
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const int ky = tap / 3, kx = tap - ky * 3;
+#pragma unroll
+        for (int c4 = 0; c4 < 4; ++c4) {                             // k-step = tap * 4 + c4: channels 4 c4 + g
+          const float bv = base[c4 * 4 * PLANE + ky * PITCH + kx];
+#pragma unroll
+          for (int m = 0; m < MT; ++m)
+            acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[m][tap * 4 + c4], bv, acc[m], 0, 0, 0);
+        }
+      }
+      const int oy = oy0 + ty, ox = ox0 + tx * 16 + lpx;
+      if (oy < a.Ho && ox < a.Wo) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            float v = acc[m][q] + bias_r[m][q];
+            if (a.relu) v = fmaxf(v, 0.f);
+            ob[((long long)(16 * m + 4 * g + q) * a.Ho + oy) * a.Wo + ox] = v;
+          }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------- 7x7, 3 -> 16 (the stem) ---
+__global__ __launch_bounds__(256) void conv7x7_c3_kernel(ConvArgs a) {
+  constexpr int CIN = 3, TAPS7 = 49, TPAD = 52, KS1 = TPAD / 4, KS = CIN * KS1;   // 13 k-steps per channel
+  constexpr int TH = 8, TW = 64, IH = TH + 6, IW = TW + 6, PITCH = 72, PLANE = IH * PITCH;
+  static_assert(PLANE % 32 == 16, "bank phase");
+  __shared__ float xs[CIN * PLANE];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lpx = lane & 15, g = lane >> 4;
+  const int b = blockIdx.z;
+  const int oy0 = blockIdx.y * TH, ox0 = blockIdx.x * TW;
+  const int iy0 = oy0 - 3, ix0 = ox0 - 3;
+  const int HW = a.H * a.W;
+
+  // A[co = lpx][k = ci * 52 + tap], taps 49..51 are zero; per-lane tile offset of tap 4 ks + g
+  float wa[KS];
+  int toff[KS1];
+#pragma unroll
+  for (int ks = 0; ks < KS1; ++ks) {
+    const int tap = 4 * ks + g;
+    const int tc = tap < TAPS7 ? tap : 0;
+    toff[ks] = (tc / 7) * PITCH + (tc % 7);
+#pragma unroll
+    for (int ci = 0; ci < CIN; ++ci)
+      wa[ci * KS1 + ks] = tap < TAPS7 ? a.w[(lpx * CIN + ci) * TAPS7 + tap] : 0.f;
+  }
+  const float* xb = a.x + (long long)b * CIN * HW;
+  const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(xb), 0, (int)((unsigned)CIN * (unsigned)HW * 4u), 0x00020000);
+  for (int e = tid; e < CIN * IH * IW; e += 256) {
+    const int ci = e / (IH * IW), r = e - ci * (IH * IW);
+    const int ry = r / IW, rx = r - ry * IW;
+    const int gy = iy0 + ry, gx = ix0 + rx;
+    const bool ok = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+    const unsigned off = ok ? ((unsigned)ci * (unsigned)HW + (unsigned)(gy * a.W + gx)) * 4u : OOBC;
+    xs[ci * PLANE + ry * PITCH + rx] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_x, off, 0, 0));
+  }
+  __syncthreads();
+
+  float bias_r[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) bias_r[q] = a.bias ? a.bias[4 * g + q] : 0.f;
+  float* ob = a.out + (long long)b * 16 * a.Ho * a.Wo;
+#pragma unroll 1
+  for (int rr = 0; rr < 2; ++rr) {
+    const int ty = wid * 2 + rr;
+#pragma unroll 1
+    for (int tx = 0; tx < TW / 16; ++tx) {
+      f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = acc0;          // two chains: 40-cycle dependent latency
+      const float* base = xs + ty * PITCH + tx * 16 + lpx;
+#pragma unroll
+      for (int ci = 0; ci < CIN; ++ci)
+#pragma unroll
+        for (int ks = 0; ks < KS1; ++ks) {
+          const float bv = base[ci * PLANE + toff[ks]];
+          if ((ks & 1) == 0) acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[ci * KS1 + ks], bv, acc0, 0, 0, 0);
+          else acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[ci * KS1 + ks], bv, acc1, 0, 0, 0);
+        }
+      const int oy = oy0 + ty, ox = ox0 + tx * 16 + lpx;
+      if (oy < a.Ho && ox < a.Wo) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float v = acc0[q] + acc1[q] + bias_r[q];
+          if (a.relu) v = fmaxf(v, 0.f);
+          ob[((long long)(4 * g + q) * a.Ho + oy) * a.Wo + ox] = v;
+        }
+      }
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int cp_conv_direct_supported(int32_t Cin, int32_t Cout, int32_t k, int32_t stride, int32_t pad) {
+  if (k == 7 && Cin == 3 && Cout == 16 && stride == 1 && pad == 3) return 1;
+  if (k == 3 && Cin == 16 && pad == 1 && ((Cout == 16 && stride == 1) || (Cout == 32 && stride == 2) ||
+                                          (Cout == 16 && stride == 2) || (Cout == 32 && stride == 1)))
+    return 1;
+  return 0;
+}
+
+extern "C" int cp_conv_direct_forward(const float* x, const float* w, const float* bias, float* out, int32_t B,
+                                      int32_t Cin, int32_t H, int32_t W, int32_t Cout, int32_t k, int32_t stride,
+                                      int32_t pad, int32_t relu, void* stream) {
+  CP_CHECK_ARG(x && w && out && B > 0 && H > 0 && W > 0);
+  if (!cp_conv_direct_supported(Cin, Cout, k, stride, pad)) return CP_EUNSUPPORTED;
+  if ((unsigned long long)Cin * H * W * 4ull >= 0x70000000ull || B > 65535) return CP_EUNSUPPORTED;
+  ConvArgs a;
+  a.x = x; a.w = w; a.bias = bias; a.out = out; a.B = B; a.H = H; a.W = W; a.relu = relu;
+  a.Ho = (H + 2 * pad - k) / stride + 1;
+  a.Wo = (W + 2 * pad - k) / stride + 1;
+  hipStream_t st = (hipStream_t)stream;
+  if (k == 7) {
+    hipLaunchKernelGGL(conv7x7_c3_kernel, dim3((a.Wo + 63) / 64, (a.Ho + 7) / 8, B), dim3(256), 0, st, a);
+  } else if (stride == 1) {
+    const dim3 grid((a.Wo + 63) / 64, (a.Ho + 7) / 8, B);
+    if (Cout == 16) hipLaunchKernelGGL((conv3x3_c16_kernel<16, 1>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((conv3x3_c16_kernel<32, 1>), grid, dim3(256), 0, st, a);
+  } else {
+    const dim3 grid((a.Wo + 63) / 64, (a.Ho + 3) / 4, B);
+    if (Cout == 16) hipLaunchKernelGGL((conv3x3_c16_kernel<16, 2>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((conv3x3_c16_kernel<32, 2>), grid, dim3(256), 0, st, a);
+  }
+  return cp_launch_status();
+}

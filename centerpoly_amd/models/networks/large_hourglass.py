@@ -11,8 +11,16 @@ the reference.  No DCN here: every layer is a dense convolution.
 """
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
-from .pose_dla_dcn import bn_act
+from ... import _C
+from .pose_dla_dcn import _conv_folded, _fold_conv_bn, _use_folded, bn_act
+
+# Inference (`prepare_inference()`): every BatchNorm is folded into its convolution (weights scaled,
+# shift as a bias) and each conv is followed by ONE fused in-place pass -- + bias (+ residual) (+ ReLU),
+# cp_bias_act_inplace -- instead of BatchNorm, add and ReLU passes; the four heads' 3x3 convolutions of a
+# stack run as one convolution (they share their input) and each head's bias + ReLU + 1x1 convolution
+# is one streaming kernel (cp_conv1x1_act_forward).  train() drops the folded copies.
 
 
 class convolution(nn.Module):
@@ -24,7 +32,15 @@ class convolution(nn.Module):
         self.bn = nn.BatchNorm2d(out_dim) if with_bn else nn.Sequential()
         self.relu = nn.ReLU(inplace=True)
 
+    def fold(self):
+        if isinstance(self.bn, nn.BatchNorm2d):
+            self._folded = _fold_conv_bn(self.conv, self.bn)
+        else:
+            self._folded = (self.conv.weight, self.conv.bias)
+
     def forward(self, x):
+        if _use_folded(self):
+            return _conv_folded(x, self.conv, self._folded, relu=True)
         if isinstance(self.bn, nn.BatchNorm2d):
             return bn_act(self.bn, self.conv(x), relu=True)     # fused BN+ReLU in training
         return self.relu(self.bn(self.conv(x)))
@@ -45,7 +61,16 @@ class residual(nn.Module):
             nn.BatchNorm2d(out_dim)) if needs_proj else nn.Sequential()
         self.relu = nn.ReLU(inplace=True)
 
+    def fold(self):
+        skip = _fold_conv_bn(self.skip[0], self.skip[1]) if len(self.skip) else None
+        self._folded = (_fold_conv_bn(self.conv1, self.bn1), _fold_conv_bn(self.conv2, self.bn2), skip)
+
     def forward(self, x):
+        if _use_folded(self):
+            f1, f2, fs = self._folded
+            skip = x if fs is None else _conv_folded(x, self.skip[0], fs, relu=False)
+            y = _conv_folded(x, self.conv1, f1, relu=True)
+            return _conv_folded(y, self.conv2, f2, relu=True, residual=skip)
         y = bn_act(self.bn1, self.conv1(x), relu=True)
         return bn_act(self.bn2, self.conv2(y), relu=True, residual=self.skip(x))
 
@@ -132,14 +157,81 @@ class exkp(nn.Module):
                     heat[-1].bias.data.fill_(-2.19)
         self.relu = nn.ReLU(inplace=True)
 
+    def prepare_inference(self):
+        """Fold every BatchNorm, concatenate each stack's head convolutions (call after loading weights).
+        Undone by train()."""
+        self.eval()
+        for m in self.modules():
+            if m is not self and hasattr(m, "fold"):
+                m.fold()
+        with torch.no_grad():
+            self._inter_folded = [(_fold_conv_bn(a[0], a[1]), _fold_conv_bn(b[0], b[1]))
+                                  for a, b in zip(self.inters_, self.cnvs_)]
+            self._heads_cat = []
+            for s in range(self.nstack):
+                fcs = [getattr(self, h)[s] for h in self.heads]
+                w = torch.cat([fc[0].conv.weight for fc in fcs], 0).contiguous()
+                b = torch.cat([fc[0].conv.bias for fc in fcs], 0).contiguous()
+                tails = [(fc[1].weight.reshape(fc[1].out_channels, -1).t().contiguous(),
+                          fc[1].bias.detach().clone(), fc[0].conv.out_channels, fc[1].out_channels) for fc in fcs]
+                self._heads_cat.append((w, b, tails))
+        return self
+
+    def train(self, mode=True):
+        if mode:
+            for m in self.modules():
+                if hasattr(m, "_folded"):
+                    m._folded = None
+            self._heads_cat = None
+            self._inter_folded = None
+        return super().train(mode)
+
+    def _heads_fast(self, s, cnv):
+        w, b, tails = self._heads_cat[s]
+        y = F.conv2d(cnv, w, None, padding=1)
+        B, ctot, H, W = y.shape
+        hw = H * W
+        out, c0 = {}, 0
+        L = _C.lib()
+        for h, (w_t, b1, hc, co) in zip(self.heads, tails):
+            o = torch.empty((B, co, H, W), dtype=torch.float32, device=y.device)
+            if co <= 32:
+                _C.check(L.cp_conv1x1_act_forward(
+                    _C.c_void_p(y.data_ptr() + 4 * c0 * hw), ctot * hw, _C.c_void_p(b.data_ptr() + 4 * c0), 1,
+                    _C.ptr(w_t), _C.ptr(b1), _C.ptr(o), B, hc, co, hw, _C.stream()), "cp_conv1x1_act_forward")
+            else:                                   # wide head (48-channel polar polygons): 32-channel slices
+                for a0 in range(0, co, 32):
+                    a1 = min(co, a0 + 32)
+                    wt = w_t[:, a0:a1].contiguous()
+                    bb = b1[a0:a1].contiguous()
+                    for i in range(B):
+                        _C.check(L.cp_conv1x1_act_forward(
+                            _C.c_void_p(y.data_ptr() + 4 * (i * ctot + c0) * hw), ctot * hw,
+                            _C.c_void_p(b.data_ptr() + 4 * c0), 1, _C.ptr(wt), _C.ptr(bb),
+                            _C.c_void_p(o.data_ptr() + 4 * (i * co + a0) * hw), 1, hc, a1 - a0, hw, _C.stream()),
+                            "cp_conv1x1_act_forward")
+            out[h] = o
+            c0 += hc
+        return out
+
     def forward(self, image):
+        fused = getattr(self, "_heads_cat", None) is not None and not self.training \
+            and not torch.is_grad_enabled() and image.is_cuda
         inter = self.pre(image)
         outs = []
         for s in range(self.nstack):
             cnv = self.cnvs[s](self.kps[s](inter))
-            outs.append({head: getattr(self, head)[s](cnv) for head in self.heads})
+            if fused and (cnv.shape[2] * cnv.shape[3]) % 4 == 0:
+                outs.append(self._heads_fast(s, cnv))
+            else:
+                outs.append({head: getattr(self, head)[s](cnv) for head in self.heads})
             if s < self.nstack - 1:
-                inter = self.relu(self.inters_[s](inter) + self.cnvs_[s](cnv))
+                if fused:
+                    fa, fb = self._inter_folded[s]
+                    t = _conv_folded(inter, self.inters_[s][0], fa, relu=False)
+                    inter = _conv_folded(cnv, self.cnvs_[s][0], fb, relu=True, residual=t)
+                else:
+                    inter = self.relu(self.inters_[s](inter) + self.cnvs_[s](cnv))
                 inter = self.inters[s](inter)
         return outs
 

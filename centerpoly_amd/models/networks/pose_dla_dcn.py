@@ -47,8 +47,36 @@ def _use_folded(m):
     return getattr(m, "_folded", None) is not None and not m.training and not torch.is_grad_enabled()
 
 
+def _conv_direct(x, conv, wb, relu):
+    """The hand-written direct convolution (cp_conv_direct_forward) for the full-resolution,
+    low-channel layers, folded-BN shift and ReLU in its epilogue; None when the shape is not one of its."""
+    kh, kw = conv.kernel_size
+    if not (x.is_cuda and x.dtype == torch.float32 and kh == kw and conv.groups == 1 and conv.dilation == (1, 1)
+            and conv.stride[0] == conv.stride[1] and conv.padding[0] == conv.padding[1]):
+        return None
+    L = _C.lib()
+    if not L.cp_conv_direct_supported(conv.in_channels, conv.out_channels, kh, conv.stride[0], conv.padding[0]):
+        return None
+    x = x.contiguous()
+    B, _, H, W = x.shape
+    Ho = (H + 2 * conv.padding[0] - kh) // conv.stride[0] + 1
+    Wo = (W + 2 * conv.padding[0] - kh) // conv.stride[0] + 1
+    out = torch.empty((B, conv.out_channels, Ho, Wo), dtype=torch.float32, device=x.device)
+    rc = L.cp_conv_direct_forward(_C.ptr(x), _C.ptr(wb[0]), _C.ptr(wb[1]), _C.ptr(out), B, conv.in_channels, H, W,
+                                  conv.out_channels, kh, conv.stride[0], conv.padding[0], 1 if relu else 0,
+                                  _C.stream())
+    if rc == -2:                                    # CP_EUNSUPPORTED (tensor too large for 32-bit offsets)
+        return None
+    _C.check(rc, "cp_conv_direct_forward")
+    return out
+
+
 def _conv_folded(x, conv, wb, relu=False, residual=None):
     """conv with folded-BN weights, then ONE fused in-place pass: + bias (+ residual) (+ ReLU)."""
+    if residual is None:
+        y = _conv_direct(x, conv, wb, relu)
+        if y is not None:
+            return y
     if not x.is_cuda:
         y = F.conv2d(x, wb[0], wb[1], conv.stride, conv.padding, conv.dilation, conv.groups)
         if residual is not None:

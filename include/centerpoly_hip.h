@@ -152,6 +152,19 @@ int cp_bias_relu_backward(const float* y, const float* grad_out, float* grad_in,
  * convolution (conv_offset_mask of DCN, src/lib/models/networks/pose_dla_dcn.py:354 via DCNv2). */
 int cp_channel_sum_accumulate(const float* x, float* out, int32_t B, int32_t C, int64_t HW, void* stream);
 
+/* Direct convolution + bias (+ ReLU) of the full-resolution, low-channel layers of the DLA base at
+ * inference (src/lib/models/networks/pose_dla_dcn.py:236-246,266-276: `base_layer` 7x7 3->16,
+ * `level0` 3x3 16->16, `level1` 3x3 s2 16->32; Conv2d(bias=False) -> BatchNorm2d -> ReLU with the
+ * BatchNorm folded by the caller: scale into `w`, shift into `bias`):
+ *   out[b][co][y][x] = act(bias[co] + sum w[co][ci][ky][kx] * x[b][ci][y*stride - pad + ky][x*stride - pad + kx])
+ * x [B][Cin][H][W], w [Cout][Cin][k][k], bias [Cout] or NULL, out [B][Cout][Ho][Wo], zero padding.
+ * Implemented shapes: (k 7, Cin 3, Cout 16, stride 1, pad 3) and (k 3, Cin 16, Cout 16|32, stride 1|2,
+ * pad 1); cp_conv_direct_supported tells, anything else returns CP_EUNSUPPORTED. */
+int cp_conv_direct_supported(int32_t Cin, int32_t Cout, int32_t k, int32_t stride, int32_t pad);
+int cp_conv_direct_forward(const float* x, const float* w, const float* bias, float* out, int32_t B, int32_t Cin,
+                           int32_t H, int32_t W, int32_t Cout, int32_t k, int32_t stride, int32_t pad,
+                           int32_t relu, void* stream);
+
 /* Output stage of a detection head at inference (the `fc` Sequential of DLASeg,
  * src/lib/models/networks/pose_dla_dcn.py:445-462: Conv2d 3x3 + bias -> ReLU -> Conv2d 1x1 + bias),
  * everything after the 3x3 convolution's matrix product, one pass:

@@ -906,3 +906,73 @@ def test_ddp_wrapper_on_gpu_matches_plain_step():
                 dist.destroy_process_group()
             os.environ["CP_FORCE_DDP"] = "0"
     np.testing.assert_allclose(losses[0], losses[1], rtol=1e-4)
+
+
+# ------------------------------------------------------- direct convolution (DLA base, full resolution) ---
+@pytest.mark.parametrize("cin,cout,k,stride,shape", [
+    (3, 16, 7, 1, (1, 40, 136)), (3, 16, 7, 1, (2, 9, 70)), (16, 16, 3, 1, (1, 24, 128)), (16, 16, 3, 1, (2, 11, 50)),
+    (16, 32, 3, 2, (1, 32, 256)), (16, 32, 3, 2, (2, 13, 70)), (16, 16, 3, 2, (1, 10, 64)), (16, 32, 3, 1, (1, 8, 64)),
+], ids=lambda v: "x".join(map(str, v)) if isinstance(v, tuple) else str(v))
+def test_direct_conv_vs_torch_conv2d(cin, cout, k, stride, shape):
+    """cp_conv_direct_forward (+ bias + ReLU epilogue) against F.conv2d fp32, including ragged tiles."""
+    B, H, W = shape
+    x = g(synth.normal("dconv/x%d%d" % (cin, H), (B, cin, H, W)))
+    w = g(synth.normal("dconv/w%d%d%d" % (cin, cout, k), (cout, cin, k, k), 0.0, 1.0 / np.sqrt(cin * k * k)))
+    b = g(synth.normal("dconv/b%d" % cout, (cout,), 0.0, 0.3))
+    pad = k // 2
+    L = _C.lib()
+    assert L.cp_conv_direct_supported(cin, cout, k, stride, pad) == 1
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    for relu in (1, 0):
+        out = torch.full((B, cout, Ho, Wo), float("nan"), device=DEV)
+        _C.check(L.cp_conv_direct_forward(_C.ptr(x), _C.ptr(w), _C.ptr(b), _C.ptr(out), B, cin, H, W, cout, k, stride,
+                                          pad, relu, _C.stream()), "cp_conv_direct_forward")
+        ref = torch.nn.functional.conv2d(x.cpu(), w.cpu(), b.cpu(), stride=stride, padding=pad)
+        if relu:
+            ref = torch.relu(ref)
+        np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), rtol=1e-4, atol=1e-5 * ref.abs().max().item())
+    assert L.cp_conv_direct_supported(8, 16, 3, 1, 1) == 0
+
+
+def test_direct_conv_full_resolution_stem():
+    """The three layers at the bench shape (1x3x1024x2048) against the library convolution on the device."""
+    x = g(synth.normal("dconv/full/x", (1, 3, 1024, 2048)))
+    L = _C.lib()
+    cin = 3
+    for cout, k, stride in ((16, 7, 1), (16, 3, 1), (32, 3, 2)):
+        w = g(synth.normal("dconv/full/w%d%d" % (cout, k), (cout, cin, k, k), 0.0, 1.0 / np.sqrt(cin * k * k)))
+        b = g(synth.normal("dconv/full/b%d%d" % (cout, k), (cout,), 0.0, 0.1))
+        pad = k // 2
+        H, W = x.shape[2:]
+        Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+        out = torch.empty((1, cout, Ho, Wo), device=DEV)
+        _C.check(L.cp_conv_direct_forward(_C.ptr(x), _C.ptr(w), _C.ptr(b), _C.ptr(out), 1, cin, H, W, cout, k, stride,
+                                          pad, 1, _C.stream()), "cp_conv_direct_forward")
+        ref = torch.relu(torch.nn.functional.conv2d(x, w, b, stride=stride, padding=pad))
+        assert (out - ref).abs().max().item() <= 1e-4 * ref.abs().max().item()
+        x, cin = out, cout
+
+
+@pytest.mark.parametrize("ns,poly,hw", [(1, 32, (128, 192)), (2, 48, (128, 128))], ids=["1stack-cart16", "2stack-polar24"])
+def test_hourglass_prepare_inference_matches_plain_eval(ns, poly, hw):
+    """Hourglass inference fusions (folded BatchNorm, fused bias/residual/ReLU epilogues, heads' 3x3
+    convolutions as one + streaming 1x1 tails, 48-channel polar head in 32-channel slices) against the
+    plain eval-mode modules, every stack's every head."""
+    from centerpoly_amd.models.networks.large_hourglass import HourglassNet
+    heads = {"hm": 8, "poly": poly, "pseudo_depth": 1, "reg": 2}
+    m = HourglassNet(heads, ns)
+    sd = {k: T(v) for k, v in cases.fill_weights({k: tuple(v.shape) for k, v in m.state_dict().items()}).items()}
+    m.load_state_dict(sd)
+    m = m.to(DEV).eval()
+    x = g(synth.normal("hg/fused/x", (2, 3) + hw))
+    with torch.no_grad():
+        plain = m(x)
+        m.prepare_inference()
+        fused = m(x)
+    assert len(plain) == len(fused) == ns
+    for a, b in zip(plain, fused):
+        for h in heads:
+            scale = a[h].abs().max().item()
+            assert (a[h] - b[h]).abs().max().item() <= 2e-4 * scale, h
+    m.train()
+    assert m._heads_cat is None and all(getattr(q, "_folded", None) is None for q in m.modules())

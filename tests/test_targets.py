@@ -153,7 +153,7 @@ def test_trainer_epoch_with_device_targets():
         opt = opts().init(["polydet", "--arch", "smallhourglass", "--device_targets", "--input_h", "256",
                            "--input_w", "256", "--batch_size", "2", "--num_iters", "2",
                            "--poly_loss", "l1+iou"])
-        Dataset = get_dataset(opt.dataset, opt.task)
+        Dataset = get_dataset("synthetic", opt.task)          # (the real dataset names need files)
         opt = opts().update_dataset_info_and_set_heads(opt, Dataset)
         ds = Dataset(opt, "train")
     opt.device = torch.device("cuda")
