@@ -41,19 +41,20 @@ template <int COUT, int STRIDE>
 __global__ __launch_bounds__(256) void conv3x3_c16_kernel(ConvArgs a) {
   constexpr int CIN = 16, MT = COUT / 16, KS = 9 * CIN / 4;          // 36 k-steps
   constexpr int TH = STRIDE == 1 ? 8 : 4, TW = 64;                   // output tile
-  constexpr int IH = (TH - 1) * STRIDE + 3, IW = (TW - 1) * STRIDE + 3;
+  constexpr int IH = (TH - 1) * STRIDE + 3;
+  constexpr int NC4 = ((TW - 1) * STRIDE + 3 + 3 + 3) / 4;           // float4 chunks per tile row (from column -4)
   constexpr int PITCH = STRIDE == 1 ? 72 : 137;                      // plane = IH * PITCH = 16 / 17 (mod 32)
   constexpr int PLANE = IH * PITCH;
-  static_assert(PITCH >= IW, "pitch");
+  static_assert(PITCH >= 4 * NC4, "pitch");
   static_assert((PLANE % 32) == (STRIDE == 1 ? 16 : 17), "bank phase of the channel planes");
-  __shared__ float xs[CIN * PLANE];
+  __shared__ __attribute__((aligned(16))) float xs[CIN * PLANE];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lpx = lane & 15, g = lane >> 4;
   const int b = blockIdx.z;
   const int oy0 = blockIdx.y * TH, ox0 = blockIdx.x * TW;
-  const int iy0 = oy0 * STRIDE - 1, ix0 = ox0 * STRIDE - 1;
+  const int iy0 = oy0 * STRIDE - 1;
   const int HW = a.H * a.W;
 
   // weights -> registers: A[co = 16 m + lpx][k = 4 ks + g], k = tap * 16 + ci
@@ -66,17 +67,47 @@ __global__ __launch_bounds__(256) void conv3x3_c16_kernel(ConvArgs a) {
       wa[m][ks] = a.w[((16 * m + lpx) * CIN + ci) * 9 + tap];
     }
 
-  // stage the halo tile: coalesced rows, zero outside the image
+  // stage the halo tile, zero outside the image.  The tile's first column is the 16-byte aligned
+  // ox0 * STRIDE - 4 (tap column kx sits at tile column 3 + kx): whole float4 chunks are inside or
+  // outside the image when W % 4 == 0, and all of a thread's loads are in flight together.
   const float* xb = a.x + (long long)b * CIN * HW;
   const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(xb), 0, (int)((unsigned)CIN * (unsigned)HW * 4u), 0x00020000);
-  for (int e = tid; e < CIN * IH * IW; e += 256) {
-    const int ci = e / (IH * IW), r = e - ci * (IH * IW);
-    const int ry = r / IW, rx = r - ry * IW;
-    const int gy = iy0 + ry, gx = ix0 + rx;
-    const bool ok = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-    const unsigned off = ok ? ((unsigned)ci * (unsigned)HW + (unsigned)(gy * a.W + gx)) * 4u : OOBC;
-    xs[ci * PLANE + ry * PITCH + rx] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_x, off, 0, 0));
+  const int gx0 = ox0 * STRIDE - 4;
+  if ((a.W & 3) == 0) {
+    constexpr int NQ = CIN * IH * NC4, NI = (NQ + 255) / 256;
+    f32x4 v[NI];
+    int dst[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int q = tid + 256 * i;
+      const int ci = q / (IH * NC4), r = q - ci * (IH * NC4);
+      const int ry = r / NC4, c4 = r - ry * NC4;
+      const int gy = iy0 + ry, gx = gx0 + 4 * c4;
+      const bool ok = q < NQ && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+      const unsigned off = ok ? ((unsigned)ci * (unsigned)HW + (unsigned)(gy * a.W + gx)) * 4u : OOBC;
+      v[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, off, 0, 0));
+      dst[i] = q < NQ ? ci * PLANE + ry * PITCH + 4 * c4 : -1;
+    }
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      if (dst[i] >= 0) {
+        if (PLANE % 4 == 0 && PITCH % 4 == 0) {
+          *reinterpret_cast<f32x4*>(&xs[dst[i]]) = v[i];
+        } else {
+          xs[dst[i]] = v[i].x; xs[dst[i] + 1] = v[i].y; xs[dst[i] + 2] = v[i].z; xs[dst[i] + 3] = v[i].w;
+        }
+      }
+    }
+  } else {
+    for (int e = tid; e < CIN * IH * (4 * NC4); e += 256) {
+      const int ci = e / (IH * 4 * NC4), r = e - ci * (IH * 4 * NC4);
+      const int ry = r / (4 * NC4), rx = r - ry * (4 * NC4);
+      const int gy = iy0 + ry, gx = gx0 + rx;
+      const bool ok = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+      const unsigned off = ok ? ((unsigned)ci * (unsigned)HW + (unsigned)(gy * a.W + gx)) * 4u : OOBC;
+      xs[ci * PLANE + ry * PITCH + rx] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_x, off, 0, 0));
+    }
   }
   __syncthreads();
 
@@ -96,7 +127,7 @@ __global__ __launch_bounds__(256) void conv3x3_c16_kernel(ConvArgs a) {
       f32x4 acc[MT];
 #pragma unroll
       for (int m = 0; m < MT; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
-      const float* base = xs + g * PLANE + (ty * STRIDE) * PITCH + (tx * 16 + lpx) * STRIDE;
+      const float* base = xs + g * PLANE + (ty * STRIDE) * PITCH + (tx * 16 + lpx) * STRIDE + 3;
 #pragma unroll
       for (int tap = 0; tap < 9; ++tap) {
         const int ky = tap / 3, kx = tap - ky * 3;
@@ -126,16 +157,16 @@ __global__ __launch_bounds__(256) void conv3x3_c16_kernel(ConvArgs a) {
 // ---------------------------------------------------------------- 7x7, 3 -> 16 (the stem) ---
 __global__ __launch_bounds__(256) void conv7x7_c3_kernel(ConvArgs a) {
   constexpr int CIN = 3, TAPS7 = 49, TPAD = 52, KS1 = TPAD / 4, KS = CIN * KS1;   // 13 k-steps per channel
-  constexpr int TH = 8, TW = 64, IH = TH + 6, IW = TW + 6, PITCH = 72, PLANE = IH * PITCH;
+  constexpr int TH = 8, TW = 64, IH = TH + 6, NC4 = 18, PITCH = 72, PLANE = IH * PITCH;   // columns -4 .. 67
   static_assert(PLANE % 32 == 16, "bank phase");
-  __shared__ float xs[CIN * PLANE];
+  __shared__ __attribute__((aligned(16))) float xs[CIN * PLANE];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lpx = lane & 15, g = lane >> 4;
   const int b = blockIdx.z;
   const int oy0 = blockIdx.y * TH, ox0 = blockIdx.x * TW;
-  const int iy0 = oy0 - 3, ix0 = ox0 - 3;
+  const int iy0 = oy0 - 3;
   const int HW = a.H * a.W;
 
   // A[co = lpx][k = ci * 52 + tap], taps 49..51 are zero; per-lane tile offset of tap 4 ks + g
@@ -153,13 +184,34 @@ __global__ __launch_bounds__(256) void conv7x7_c3_kernel(ConvArgs a) {
   const float* xb = a.x + (long long)b * CIN * HW;
   const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(xb), 0, (int)((unsigned)CIN * (unsigned)HW * 4u), 0x00020000);
-  for (int e = tid; e < CIN * IH * IW; e += 256) {
-    const int ci = e / (IH * IW), r = e - ci * (IH * IW);
-    const int ry = r / IW, rx = r - ry * IW;
-    const int gy = iy0 + ry, gx = ix0 + rx;
-    const bool ok = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-    const unsigned off = ok ? ((unsigned)ci * (unsigned)HW + (unsigned)(gy * a.W + gx)) * 4u : OOBC;
-    xs[ci * PLANE + ry * PITCH + rx] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_x, off, 0, 0));
+  const int gx0 = ox0 - 4;                                          // aligned; tap column kx sits at tile column 1 + kx
+  if ((a.W & 3) == 0) {
+    constexpr int NQ = CIN * IH * NC4, NI = (NQ + 255) / 256;
+    f32x4 v[NI];
+    int dst[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int q = tid + 256 * i;
+      const int ci = q / (IH * NC4), r = q - ci * (IH * NC4);
+      const int ry = r / NC4, c4 = r - ry * NC4;
+      const int gy = iy0 + ry, gx = gx0 + 4 * c4;
+      const bool ok = q < NQ && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+      const unsigned off = ok ? ((unsigned)ci * (unsigned)HW + (unsigned)(gy * a.W + gx)) * 4u : OOBC;
+      v[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, off, 0, 0));
+      dst[i] = q < NQ ? ci * PLANE + ry * PITCH + 4 * c4 : -1;
+    }
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+      if (dst[i] >= 0) *reinterpret_cast<f32x4*>(&xs[dst[i]]) = v[i];
+  } else {
+    for (int e = tid; e < CIN * IH * (4 * NC4); e += 256) {
+      const int ci = e / (IH * 4 * NC4), r = e - ci * (IH * 4 * NC4);
+      const int ry = r / (4 * NC4), rx = r - ry * (4 * NC4);
+      const int gy = iy0 + ry, gx = gx0 + rx;
+      const bool ok = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+      const unsigned off = ok ? ((unsigned)ci * (unsigned)HW + (unsigned)(gy * a.W + gx)) * 4u : OOBC;
+      xs[ci * PLANE + ry * PITCH + rx] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_x, off, 0, 0));
+    }
   }
   __syncthreads();
 
@@ -173,7 +225,7 @@ __global__ __launch_bounds__(256) void conv7x7_c3_kernel(ConvArgs a) {
 #pragma unroll 1
     for (int tx = 0; tx < TW / 16; ++tx) {
       f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = acc0;          // two chains: 40-cycle dependent latency
-      const float* base = xs + ty * PITCH + tx * 16 + lpx;
+      const float* base = xs + ty * PITCH + tx * 16 + lpx + 1;
 #pragma unroll
       for (int ci = 0; ci < CIN; ++ci)
 #pragma unroll

@@ -71,6 +71,46 @@ def _conv_direct(x, conv, wb, relu):
     return out
 
 
+class _DirectConvFn(torch.autograd.Function):
+    """Training forward of a bias-free convolution through the direct kernel; the gradients are the
+    library's (torch.nn.grad), only for the inputs that need them."""
+
+    @staticmethod
+    def forward(ctx, x, weight, stride, pad):
+        ctx.save_for_backward(x, weight)
+        ctx.cfg = (stride, pad)
+        B, cin, H, W = x.shape
+        cout, _, k, _ = weight.shape
+        Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+        out = torch.empty((B, cout, Ho, Wo), dtype=torch.float32, device=x.device)
+        _C.check(_C.lib().cp_conv_direct_forward(_C.ptr(x), _C.ptr(weight), None, _C.ptr(out), B, cin, H, W, cout, k,
+                                                 stride, pad, 0, _C.stream()), "cp_conv_direct_forward")
+        return out
+
+    @staticmethod
+    def backward(ctx, go):
+        x, weight = ctx.saved_tensors
+        stride, pad = ctx.cfg
+        go = go.contiguous()
+        gx = torch.nn.grad.conv2d_input(x.shape, weight, go, stride=stride, padding=pad) \
+            if ctx.needs_input_grad[0] else None
+        gw = torch.nn.grad.conv2d_weight(x, weight.shape, go, stride=stride, padding=pad) \
+            if ctx.needs_input_grad[1] else None
+        return gx, gw, None, None
+
+
+def conv_train(conv, x):
+    """conv(x) in training: the direct kernel's forward for the shapes it has, the library otherwise."""
+    kh, kw = conv.kernel_size
+    if (x.is_cuda and x.dtype == torch.float32 and conv.bias is None and kh == kw and conv.groups == 1
+            and conv.dilation == (1, 1) and conv.stride[0] == conv.stride[1] and conv.padding[0] == conv.padding[1]
+            and x.shape[1] * x.shape[2] * x.shape[3] * 4 < 0x70000000
+            and _C.lib().cp_conv_direct_supported(conv.in_channels, conv.out_channels, kh, conv.stride[0],
+                                                  conv.padding[0])):
+        return _DirectConvFn.apply(x.contiguous(), conv.weight, conv.stride[0], conv.padding[0])
+    return conv(x)
+
+
 def _conv_folded(x, conv, wb, relu=False, residual=None):
     """conv with folded-BN weights, then ONE fused in-place pass: + bias (+ residual) (+ ReLU)."""
     if residual is None:
@@ -332,7 +372,7 @@ class DLA(nn.Module):
         elif self.training and x.is_cuda and all(len(q) == 3 for q in (self.base_layer, self.level0,
                                                                         self.level1)):
             for seq in (self.base_layer, self.level0, self.level1):
-                x = bn_act(seq[1], seq[0](x), relu=True)
+                x = bn_act(seq[1], conv_train(seq[0], x), relu=True)
                 if seq is not self.base_layer:
                     pyramid.append(x)
             first_tree = 2

@@ -953,7 +953,7 @@ def test_direct_conv_full_resolution_stem():
         x, cin = out, cout
 
 
-@pytest.mark.parametrize("ns,poly,hw", [(1, 32, (128, 192)), (2, 48, (128, 128))], ids=["1stack-cart16", "2stack-polar24"])
+@pytest.mark.parametrize("ns,poly,hw", [(1, 32, (128, 256)), (2, 48, (128, 128))], ids=["1stack-cart16", "2stack-polar24"])
 def test_hourglass_prepare_inference_matches_plain_eval(ns, poly, hw):
     """Hourglass inference fusions (folded BatchNorm, fused bias/residual/ReLU epilogues, heads' 3x3
     convolutions as one + streaming 1x1 tails, 48-channel polar head in 32-channel slices) against the
@@ -976,3 +976,22 @@ def test_hourglass_prepare_inference_matches_plain_eval(ns, poly, hw):
             assert (a[h] - b[h]).abs().max().item() <= 2e-4 * scale, h
     m.train()
     assert m._heads_cat is None and all(getattr(q, "_folded", None) is None for q in m.modules())
+
+
+def test_direct_conv_training_function_gradients():
+    """conv_train (direct forward, library gradients) against nn.Conv2d autograd."""
+    from centerpoly_amd.models.networks.pose_dla_dcn import conv_train
+    for cin, cout, k, stride in ((3, 16, 7, 1), (16, 16, 3, 1), (16, 32, 3, 2)):
+        conv = torch.nn.Conv2d(cin, cout, k, stride, k // 2, bias=False).to(DEV)
+        x1 = g(synth.normal("dconv/train/x%d" % cin, (2, cin, 24, 64))).requires_grad_(True)
+        x2 = x1.detach().clone().requires_grad_(True)
+        go = g(synth.normal("dconv/train/go%d%d" % (cout, stride), (2, cout, 24 // stride, 64 // stride)))
+        y1 = conv_train(conv, x1)
+        y1.backward(go)
+        gw1 = conv.weight.grad.clone()
+        conv.zero_grad()
+        y2 = conv(x2)
+        y2.backward(go)
+        torch.testing.assert_close(y1, y2, rtol=1e-4, atol=1e-5)
+        torch.testing.assert_close(x1.grad, x2.grad, rtol=1e-4, atol=1e-5)
+        torch.testing.assert_close(gw1, conv.weight.grad, rtol=1e-4, atol=1e-4)
