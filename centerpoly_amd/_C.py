@@ -62,6 +62,7 @@ _SIGNATURES = {
     "cp_preprocess_warp_normalize": (c_int32, [_P, c_int32, c_int32, _P, _P, _P, c_int32, c_int32, c_int32, _P, _P]),
     "cp_color_aug_workspace_bytes": (c_size_t, []),
     "cp_color_aug_normalize": (c_int32, [_P, c_int64, c_int32, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
+    "cp_instance_masks": (c_int32, [_P, _P, c_int32, c_int32, c_int32, c_int32, _P, _P, _P]),
     "cp_polydet_post_process": (c_int32, [_P, _P, c_float, c_int32, c_int32, c_int32, _P, _P]),
     "cp_polydet_targets_workspace_bytes": (c_size_t, [POINTER(TargetShape)]),
     "cp_polydet_targets": (c_int32, [POINTER(TargetShape)] + [_P] * 19 + [_P, c_size_t, _P]),

@@ -106,7 +106,74 @@ class PolygonDataset(data.Dataset):
         return 0.0
 
 
-class CITYSCAPES(PolygonDataset):
+def _to_float(x):
+    return float("{:.2f}".format(x))
+
+
+class CityscapesWriterMixin(object):
+    """format_and_write_to_cityscapes (src/lib/datasets/dataset/cityscapes.py:196-283): per image a text
+    file `<image>.txt` listing `masks/<image>_<k>.png <label id> <confidence>` and the instance masks as
+    8-bit PNG files, instances processed in ascending depth, nearer confident ones hiding farther ones.
+    The masks are rasterised on the GPU (cp_instance_masks); selection, ordering, naming and the file
+    output (PIL, like the reference) stay on the host."""
+    canvas = (2048, 1024)                                    # (width, height), hard-coded by the reference
+    no_mask_labels = ("pole", "traffic sign", "traffic light")
+
+    def image_instances(self, per_class):
+        params = []
+        for cls_ind in per_class:
+            if cls_ind == "fg":
+                continue
+            for row in per_class[cls_ind]:
+                if row[4] > self.opt.thresh:
+                    poly = [_to_float(v) for v in row[5:-1]]
+                    pts = [(int(x), int(y)) for x, y in zip(poly[0::2], poly[1::2])]
+                    params.append((pts, row[4], self.class_name[cls_ind], row[-1]))
+        return sorted(params, key=lambda a: a[-1])
+
+    def instance_masks(self, params, device=None):
+        """Occlusion-ordered masks of depth-sorted instances: (uint8 [n, H, W] host array, counts [n])."""
+        import torch
+
+        from ... import _C
+        W, H = self.canvas
+        n = len(params)
+        if n == 0:
+            return np.zeros((0, H, W), np.uint8), np.zeros((0,), np.int32)
+        if n > 128:
+            raise ValueError("more than 128 instances in one image (max_per_image = K <= 128)")
+        N = len(params[0][0])
+        dev = device or torch.device("cuda")
+        poly = torch.tensor([p[0] for p in params], dtype=torch.int32).reshape(n, N, 2).to(dev)
+        flags = torch.tensor([(0 if p[2] in self.no_mask_labels else 1) | (2 if p[1] >= 0.5 else 0) for p in params],
+                             dtype=torch.uint8).to(dev)
+        masks = torch.empty((n, H, W), dtype=torch.uint8, device=dev)
+        counts = torch.empty((n,), dtype=torch.int32, device=dev)
+        _C.check(_C.lib().cp_instance_masks(_C.ptr(poly), _C.ptr(flags), n, N, H, W, _C.ptr(masks), _C.ptr(counts),
+                                            _C.stream()), "cp_instance_masks")
+        return masks.cpu().numpy(), counts.cpu().numpy()
+
+    def format_and_write_to_cityscapes(self, all_bboxes, save_dir):
+        from PIL import Image
+        id_to_file = {im["id"]: im["file_name"] for im in self.coco.imgs.values()}
+        masks_dir = os.path.join(save_dir, "masks")
+        os.makedirs(masks_dir, exist_ok=True)
+        for image_id in all_bboxes:
+            base = os.path.basename(id_to_file[int(image_id)])
+            params = self.image_instances(all_bboxes[image_id])
+            masks, counts = self.instance_masks(params)
+            count = 0
+            with open(os.path.join(save_dir, base.replace(".png", ".txt")), "w") as text_file:
+                for (pts, score, label, depth), mask, nz in zip(params, masks, counts):
+                    if label not in self.no_mask_labels and nz > 100:
+                        name = base.replace(".png", "_" + str(count) + ".png")
+                        text_file.write("masks/" + name + " " + str(self.label_to_id[label]) + " "
+                                        + str(min(1, score * 1.2)) + "\n")
+                        count += 1
+                        Image.fromarray(mask).save(os.path.join(masks_dir, name))
+
+
+class CITYSCAPES(CityscapesWriterMixin, PolygonDataset):
     """src/lib/datasets/dataset/cityscapes.py:39-110."""
     name = "cityscapes"
     annot_subdir = os.path.join("cityscapesStuff", "BBoxes")
@@ -119,10 +186,23 @@ class CITYSCAPES(PolygonDataset):
                          "bicycle": 0.0322057384531526, "pole": 0.34640870553158515,
                          "traffic sign": 0.16402335310072175, "traffic light": 0.07813700573319936}
 
+    label_to_id = {"person": 24, "rider": 25, "car": 26, "truck": 27, "bus": 28, "train": 31, "motorcycle": 32,
+                   "bicycle": 33, "pole": -1, "traffic sign": -1, "traffic light": -1}
+
     def annot_file(self, split):
         if split == "test":
             return "test.json"
         return "%s%d_regular_interval.json" % ("val" if split == "val" else "train", self.opt.nbr_points)
+
+    def run_eval(self, results, save_dir):
+        """cityscapes.py:400-432 up to the vendored evaluator: results.json + the per-image mask files the
+        Cityscapes instance-level evaluation reads (evalInstanceLevelSemanticLabeling itself is outside the
+        accelerated path)."""
+        super(CITYSCAPES, self).run_eval(results, save_dir)
+        res_dir = os.path.join(save_dir, "results")
+        os.makedirs(res_dir, exist_ok=True)
+        self.format_and_write_to_cityscapes(results, res_dir)
+        return 0.0
 
 
 class KITTIPOLY(PolygonDataset):

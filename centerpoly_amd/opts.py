@@ -91,6 +91,8 @@ class opts(object):
         p.add_argument("--test_scales", type=str, default="1")
         p.add_argument("--nms", action="store_true")
         p.add_argument("--K", type=int, default=128)
+        p.add_argument("--thresh", type=float, default=0.05,
+                       help="threshold for the outputs kept for evaluation (result writer)")
         p.add_argument("--not_prefetch_test", action="store_true")
         p.add_argument("--fix_res", action="store_true")
         p.add_argument("--keep_res", action="store_true")

@@ -177,6 +177,18 @@ int cp_conv1x1_act_forward(const float* y, int64_t y_bstride, const float* in_bi
                            const float* w_t, const float* bias, float* out, int32_t B, int32_t Cin,
                            int32_t Cout, int64_t HW, void* stream);
 
+/* ------------------------------------------------ evaluation result writer --
+ * cp_instance_masks: the per-instance rasterisation of CITYSCAPES.format_and_write_to_cityscapes
+ * (src/lib/datasets/dataset/cityscapes.py:240-272) for the instances of ONE image, already sorted by
+ * ascending depth: polygon fill + outline, radius-2 dilation of the closed Bresenham contour, removal of
+ * what nearer instances with score >= 0.5 hide.
+ *   poly   DEVICE int32 [n][N][2]  integer (x, y) vertices      flags  DEVICE uint8 [n]: bit 0 = the label
+ *   has masks (not pole / traffic sign / traffic light), bit 1 = score >= 0.5 (hides farther instances)
+ *   masks  DEVICE uint8 [n][H][W] out, 0 / 255                  counts DEVICE int32 [n] out, non-zero pixels
+ * n <= 128, N <= 64.  Equal to PIL 12.2's drawing mask for mask (tests/golden/writer_*.npz). */
+int cp_instance_masks(const int32_t* poly, const uint8_t* flags, int32_t n, int32_t N, int32_t H, int32_t W,
+                      uint8_t* masks, int32_t* counts, void* stream);
+
 /* ------------------------------------------------ detector pre/post-processing --
  * cp_preprocess_warp_normalize: the cv2 stage of BaseDetector.pre_process
  * (src/lib/detectors/base_detector.py:66-87): cv2.warpAffine(image, trans_input, (dst_w, dst_h),
