@@ -975,6 +975,12 @@ int cp_dcn_bwd_data2(const cp_dcn_shape* s, const float* x, const float* offset,
                      float* grad_mask, int64_t grad_mask_bstride, void* workspace, size_t workspace_bytes,
                      hipStream_t st);
 
+// dcn_bwd_weight.hip: the weight gradient with columns sampled straight into the MFMA operand
+bool cp_dcn_bwd_weight2_supported(const cp_dcn_shape* s);
+int cp_dcn_bwd_weight2(const cp_dcn_shape* s, const float* x, const float* offset, int64_t offset_bstride,
+                       const float* mask, int64_t mask_bstride, int32_t mask_is_logit, const float* grad_out,
+                       float* grad_weight, hipStream_t st);
+
 // A/B switch for timing runs (tools/probe_dcn_bwd.py): CP_DCN_BWD_V1=1 keeps the round-1 data kernel.
 // Read once per process, never on the call path.
 static bool use_v1_data_kernel() {
@@ -1044,7 +1050,14 @@ extern "C" int cp_dcn_v2_backward(const cp_dcn_shape* s, const float* x, const f
       hipLaunchKernelGGL(dcn_bwd_data_kernel, dim3(tiles, s->B), dim3(256), lds, st, a);
     }
   }
-  if (grad_weight) {
+  bool weight_done = false;
+  if (grad_weight && cp_dcn_bwd_weight2_supported(s) && !use_v1_data_kernel()) {
+    const int rc = cp_dcn_bwd_weight2(s, x, offset, offset_bstride, mask, mask_bstride, mask_is_logit, grad_out,
+                                      grad_weight, st);
+    if (rc != CP_OK) return rc;
+    weight_done = true;
+  }
+  if (grad_weight && !weight_done) {
     const bool tiled_w = same_size;
     const int slab = s->Cout <= 64 ? 64 : COC;
     const int slabs = (s->Cout + slab - 1) / slab;
