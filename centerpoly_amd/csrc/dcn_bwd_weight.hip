@@ -10,8 +10,8 @@
 // The contraction runs over PIXELS: per k-step of 4 pixels
 //   A[co][px]  = grad_out, from an LDS copy of the tile's grad_out ([co][128 px], staged per tile);
 //   B[px][ci]  = the column value of ONE tap, computed by the lane that owns (px = lane >> 4, ci = lane & 15)
-//                right before the MFMA: recipe (ly, lx, mask, region index) of (px, tap) from LDS, four corner
-//                reads from the LDS-staged input region, five VALU operations -- no column tile in LDS, all
+//                right before the MFMA: the (px, tap) recipe from LDS (four corner weights with the mask folded in,
+//                region index), four corner reads from the LDS-staged input region, four fmas -- no column tile in LDS, all
 //                16 columns of every n-tile useful (the round-1 kernel padded 36 columns to 48 and wrote /
 //                re-read a column tile per chunk);
 //   D[co][ci]  += one 16x16 tile per (tap, 16 output channels).
@@ -51,7 +51,8 @@ __global__ __launch_bounds__(512, 4) void dcn_bwd_weight2_kernel(W2Args a) {
   __shared__ float goT[SLAB * KC * TAPS];          // [co][px] (pitch LDG); reused as [co][ci * 9 + tap] for the flush
   static_assert(KC * TAPS >= LDG, "flush tile fits the grad_out buffer");
   __shared__ __attribute__((aligned(16))) float xreg[KC * RSZP];
-  __shared__ float4 rec[TAPS * NPX];               // per (tap, pixel): ly, lx, mask, region index
+  __shared__ float4 rec[TAPS * NPX];               // per (tap, pixel): the four corner weights times the mask
+  __shared__ int recb[TAPS * NPX];                 // ... and the region index (>= 0), -2 (nothing) or the cold-path code
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -149,7 +150,9 @@ __global__ __launch_bounds__(512, 4) void dcn_bwd_weight2_kernel(W2Args a) {
         const bool in_region = inside && ry >= 0 && ry + 1 < RH && rx >= 0 && rx + 1 < RWD;
         const int rb = in_region ? ry * RWD + rx : (inside ? -(3 + (((y0c * a.W + x0c) << 4) | vb)) : -2);
         lane_fb |= rb <= -3;
-        rec[e] = make_float4(sy - fy, sx - fx, p_ok ? m : 0.f, __int_as_float(rb));
+        const float ly = sy - fy, lx = sx - fx, hy = 1.f - ly, hx = 1.f - lx, mm = p_ok ? m : 0.f;
+        rec[e] = make_float4(hy * hx * mm, hy * lx * mm, ly * hx * mm, ly * lx * mm);
+        recb[e] = rb;
       }
     }
     // ---- input region of the chunk's 16 channels: 16-byte chunks (W % 4 == 0) or scalars ----
@@ -198,12 +201,10 @@ __global__ __launch_bounds__(512, 4) void dcn_bwd_weight2_kernel(W2Args a) {
     // ---- contraction over the tile's 128 pixels ----
     const float* xw = xreg + lci * RSZP;
     auto column = [&](int t, int q) -> float {      // col value of (tap t, pixel slot q) for channel c0 + lci
-      const float4 rc = rec[t * NPX + q];
-      const int rb = __float_as_int(rc.w);
+      const float4 w = rec[t * NPX + q];
+      const int rb = recb[t * NPX + q];
       const int rbc = max(rb, 0);
-      const float v00 = xw[rbc], v01 = xw[rbc + 1], v10 = xw[rbc + RWD], v11 = xw[rbc + RWD + 1];
-      const float ly = rc.x, lx = rc.y, hy = 1.f - ly, hx = 1.f - lx;
-      const float val = (hy * hx * v00 + hy * lx * v01 + ly * hx * v10 + ly * lx * v11) * rc.z;
+      const float val = w.x * xw[rbc] + w.y * xw[rbc + 1] + w.z * xw[rbc + RWD] + w.w * xw[rbc + RWD + 1];
       return rb >= 0 ? val : 0.f;
     };
 #pragma unroll 4
@@ -231,8 +232,8 @@ __global__ __launch_bounds__(512, 4) void dcn_bwd_weight2_kernel(W2Args a) {
         for (int which = 0; which < 2; ++which) {
           if (which == 1 && (ks & 7) != wid) continue;
           const int t = which == 0 ? wid : 8;
-          const float4 rc = rec[t * NPX + q];
-          const int rb = __float_as_int(rc.w);
+          const float4 w = rec[t * NPX + q];
+          const int rb = recb[t * NPX + q];
           float bv = 0.f;
           if (rb <= -3 && ci_ok) {
             const int code = -rb - 3;
@@ -243,8 +244,7 @@ __global__ __launch_bounds__(512, 4) void dcn_bwd_weight2_kernel(W2Args a) {
             const float* p = xc + fbase;
             const float v00 = (vb & 1u) ? p[0] : 0.f, v01 = (vb & 2u) ? p[dx] : 0.f;
             const float v10 = (vb & 4u) ? p[dy] : 0.f, v11 = (vb & 8u) ? p[dy + dx] : 0.f;
-            const float ly = rc.x, lx = rc.y, hy = 1.f - ly, hx = 1.f - lx;
-            bv = (hy * hx * v00 + hy * lx * v01 + ly * hx * v10 + ly * lx * v11) * rc.z;
+            bv = w.x * v00 + w.y * v01 + w.z * v10 + w.w * v11;
           }
           if (__builtin_amdgcn_ballot_w64(rb <= -3) == 0ull) continue;     // (wave-uniform skip)
 #pragma unroll
