@@ -949,9 +949,17 @@ __global__ __launch_bounds__(256) void dcn_bwd_bias_kernel(const float* __restri
   const long long s0 = (long long)blockIdx.y * BIAS_SEG;
   const long long s1 = s0 + BIAS_SEG < total ? s0 + BIAS_SEG : total;
   float s = 0.f;
-  for (long long i = s0 + threadIdx.x; i < s1; i += 256) {
-    const long long b = i / HWo, p = i - b * HWo;
-    s += go[(b * Cout + co) * HWo + p];
+  if ((HWo & 3) == 0) {                       // 16-byte loads: a segment never straddles an image (BIAS_SEG % 4 == 0)
+    for (long long i = s0 + 4 * threadIdx.x; i < s1; i += 1024) {
+      const long long b = i / HWo, p = i - b * HWo;
+      const float4 v = *reinterpret_cast<const float4*>(go + (b * Cout + co) * HWo + p);
+      s += (v.x + v.y) + (v.z + v.w);
+    }
+  } else {
+    for (long long i = s0 + threadIdx.x; i < s1; i += 256) {
+      const long long b = i / HWo, p = i - b * HWo;
+      s += go[(b * Cout + co) * HWo + p];
+    }
   }
   s = cp_wave_sum(s);
   __shared__ float red[4];
@@ -979,7 +987,7 @@ int cp_dcn_bwd_data2(const cp_dcn_shape* s, const float* x, const float* offset,
 bool cp_dcn_bwd_weight2_supported(const cp_dcn_shape* s);
 int cp_dcn_bwd_weight2(const cp_dcn_shape* s, const float* x, const float* offset, int64_t offset_bstride,
                        const float* mask, int64_t mask_bstride, int32_t mask_is_logit, const float* grad_out,
-                       float* grad_weight, hipStream_t st);
+                       float* grad_weight, float* grad_bias, hipStream_t st);
 
 // A/B switch for timing runs (tools/probe_dcn_bwd.py): CP_DCN_BWD_V1=1 keeps the round-1 data kernel.
 // Read once per process, never on the call path.
@@ -1052,10 +1060,12 @@ extern "C" int cp_dcn_v2_backward(const cp_dcn_shape* s, const float* x, const f
   }
   bool weight_done = false;
   if (grad_weight && cp_dcn_bwd_weight2_supported(s) && !use_v1_data_kernel()) {
+    // (grad_bias rides along: the weight kernel has every grad_out tile in LDS anyway)
     const int rc = cp_dcn_bwd_weight2(s, x, offset, offset_bstride, mask, mask_bstride, mask_is_logit, grad_out,
-                                      grad_weight, st);
+                                      grad_weight, grad_bias, st);
     if (rc != CP_OK) return rc;
     weight_done = true;
+    grad_bias = nullptr;
   }
   if (grad_weight && !weight_done) {
     const bool tiled_w = same_size;

@@ -37,6 +37,7 @@ struct W2Args {
   const float* mask;
   const float* go;
   float* gw;
+  float* gb;                  // grad_bias (may be null): summed by the workgroups of the first input-channel chunk
   long long offset_bstride, mask_bstride;
   int B, Cin, H, W, Cout;
   int pad, dil, mask_is_logit;
@@ -50,6 +51,7 @@ __global__ __launch_bounds__(512, 4) void dcn_bwd_weight2_kernel(W2Args a) {
   constexpr int LDG = NPX + 2;                     // grad_out row pitch 130 = 2 (mod 32): lanes (co, px) hit 32 banks
   __shared__ float goT[SLAB * KC * TAPS];          // [co][px] (pitch LDG); reused as [co][ci * 9 + tap] for the flush
   static_assert(KC * TAPS >= LDG, "flush tile fits the grad_out buffer");
+  static_assert(SLAB * 8 == 512 && NPX == 128, "bias sum: one thread per (output channel, 16 pixels)");
   __shared__ __attribute__((aligned(16))) float xreg[KC * RSZP];
   __shared__ float4 rec[TAPS * NPX];               // per (tap, pixel): the four corner weights times the mask
   __shared__ int recb[TAPS * NPX];                 // ... and the region index (>= 0), -2 (nothing) or the cold-path code
@@ -116,6 +118,8 @@ __global__ __launch_bounds__(512, 4) void dcn_bwd_weight2_kernel(W2Args a) {
       gq[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_go, o, 0, 0));
     }
   };
+  float gbsum = 0.f;                                 // thread (co = tid >> 3, part = tid & 7): 16 pixels of a grad_out row
+  const bool do_bias = a.gb != nullptr && blockIdx.y == 0;
   if (t_begin < t_end) fetch(t_begin);
   for (int tile = t_begin; tile < t_end; ++tile) {
     int ty0, tx0;
@@ -197,6 +201,13 @@ __global__ __launch_bounds__(512, 4) void dcn_bwd_weight2_kernel(W2Args a) {
     }
     const bool any_fallback = __syncthreads_or(lane_fb ? 1 : 0) != 0;   // also publishes rec / xreg / goT
     if (tile + 1 < t_end) fetch(tile + 1);          // lands during the contraction below
+    if (do_bias) {                                   // grad_bias[co] += sum over the tile's pixels of grad_out
+      const float* row = goT + (tid >> 3) * LDG + (tid & 7) * 16;
+      float sm = 0.f;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) sm += row[i];
+      gbsum += sm;
+    }
 
     // ---- contraction over the tile's 128 pixels ----
     const float* xw = xreg + lci * RSZP;
@@ -258,6 +269,12 @@ __global__ __launch_bounds__(512, 4) void dcn_bwd_weight2_kernel(W2Args a) {
     }
   }
 
+  if (do_bias) {
+    gbsum += __shfl_xor(gbsum, 1, 64);
+    gbsum += __shfl_xor(gbsum, 2, 64);
+    gbsum += __shfl_xor(gbsum, 4, 64);
+    if ((tid & 7) == 0 && co0 + (tid >> 3) < a.Cout) atomicAdd(&a.gb[co0 + (tid >> 3)], gbsum);
+  }
   // ---- flush: the partial gradient goes through LDS so that grad_weight receives ONE coalesced atomic add
   // per element and workgroup (rows of 16 ci x 9 taps = 144 contiguous floats per output channel); tap 8's
   // eight per-wave partial sums meet in LDS first.  D[co = 16 m + 4 g + reg][ci = lci].
@@ -294,9 +311,9 @@ bool cp_dcn_bwd_weight2_supported(const cp_dcn_shape* s) {
 
 int cp_dcn_bwd_weight2(const cp_dcn_shape* s, const float* x, const float* offset, int64_t offset_bstride,
                        const float* mask, int64_t mask_bstride, int32_t mask_is_logit, const float* grad_out,
-                       float* grad_weight, hipStream_t st) {
+                       float* grad_weight, float* grad_bias, hipStream_t st) {
   W2Args a;
-  a.x = x; a.offset = offset; a.mask = mask; a.go = grad_out; a.gw = grad_weight;
+  a.x = x; a.offset = offset; a.mask = mask; a.go = grad_out; a.gw = grad_weight; a.gb = grad_bias;
   a.offset_bstride = offset_bstride; a.mask_bstride = mask_bstride;
   a.B = s->B; a.Cin = s->Cin; a.H = s->H; a.W = s->W; a.Cout = s->Cout;
   a.pad = s->pad; a.dil = s->dil; a.mask_is_logit = mask_is_logit;
