@@ -142,12 +142,16 @@ __global__ __launch_bounds__(256) void dcn_bwd_wperm_kernel(const float* __restr
 // (SQ_VALU_MFMA_COEXEC_CYCLES = 0 in every profile of this kernel), so the two phases of one SIMD never
 // overlap whichever waves run them.
 template <int CP, int TH, bool WANT_GX>
-__global__ __launch_bounds__(TH * 64) void dcn_bwd_data2_kernel(D2Args a) {
+__global__ __launch_bounds__(TH * 64, TH / 4) void dcn_bwd_data2_kernel(D2Args a) {
   using G = Geo<TH>;
   constexpr int RSZ = G::RSZ, RSZP = G::RSZP, RH = G::RH, NPX = G::NPX, NTHR = G::NTHR;
   constexpr int NS = CP / 64;                              // 64-wide output-channel slabs
   constexpr int NB = CP / 4;                               // B-operand registers per lane
-  __shared__ f32x4 Abuf[2][A_F4];                          // weights of one (chunk, slab), fragment order
+  // TH = 8: two waves per SIMD, weight stages double-buffered.  TH = 12 (64 output channels only): three waves
+  // per SIMD -- more latency hiding for the LDS-bound consumption -- which leaves LDS for ONE weight buffer.
+  constexpr bool DBUF = TH <= 8;
+  static_assert(DBUF || NS == 1, "the single-buffer schedule is written for one slab per chunk");
+  __shared__ f32x4 Abuf[DBUF ? 2 : 1][A_F4];               // weights of one (chunk, slab), fragment order
   __shared__ float xreg[KC * RSZP];                        // input region of the chunk's channels
   __shared__ __attribute__((aligned(16))) unsigned long long gacc[WANT_GX ? KC * RSZP : 2];  // fixed-point grad_x region sums
   __shared__ float4 rec[TAPS * NPX];                       // per (tap, pixel): ly, lx, mask, region index
@@ -476,24 +480,40 @@ __global__ __launch_bounds__(TH * 64) void dcn_bwd_data2_kernel(D2Args a) {
       for (int t = 0; t < TAPS; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
       const unsigned long long tw0 = CP_T();
       (void)tw0;
-      load_x(cs0 + i);                                              // lands during the matrix phase
-      static_for<0, NS>([&](auto S_) __attribute__((always_inline)) {
-        constexpr int s = decltype(S_)::value;
-        const int buf = stage & 1;
-        __builtin_amdgcn_s_waitcnt(0x0f70);                         // vmcnt(0): this stage's DMA (and the region loads)
-        __syncthreads();                                            // ... of every wave; previous consumption finished
-        const int ni = s + 1 < NS ? i : i + 1, ns = s + 1 < NS ? s + 1 : 0;
-        if (ni < n) dma_a((cs0 + ni) * NS + ns, buf ^ 1);
-        ++stage;
-        mfma_slab(S_, buf);
-      });
-      CP_ACC(t_mfma, tw0);
-      const unsigned long long tf0 = CP_T();
-      (void)tf0;
-      store_x();                                                    // (loads waited for at the stage barrier above)
-      if (WANT_GX && i >= 1) flush((cs0 + i - 1) * KC);
-      __syncthreads();                                              // region + emptied sums visible
-      CP_ACC(t_flush, tf0);
+      if constexpr (DBUF) {
+        load_x(cs0 + i);                                            // lands during the matrix phase
+        static_for<0, NS>([&](auto S_) __attribute__((always_inline)) {
+          constexpr int s = decltype(S_)::value;
+          const int buf = stage & 1;
+          __builtin_amdgcn_s_waitcnt(0x0f70);                       // vmcnt(0): this stage's DMA (and the region loads)
+          __syncthreads();                                          // ... of every wave; previous consumption finished
+          const int ni = s + 1 < NS ? i : i + 1, ns = s + 1 < NS ? s + 1 : 0;
+          if (ni < n) dma_a((cs0 + ni) * NS + ns, buf ^ 1);
+          ++stage;
+          mfma_slab(S_, buf);
+        });
+        CP_ACC(t_mfma, tw0);
+        const unsigned long long tf0 = CP_T();
+        (void)tf0;
+        store_x();                                                  // (loads waited for at the stage barrier above)
+        if (WANT_GX && i >= 1) flush((cs0 + i - 1) * KC);
+        __syncthreads();                                            // region + emptied sums visible
+        CP_ACC(t_flush, tf0);
+      } else {
+        __builtin_amdgcn_s_waitcnt(0x0f70);                         // vmcnt(0): this chunk's weight DMA has landed
+        __syncthreads();                                            // ... for every wave; previous consumption finished
+        mfma_slab(std::integral_constant<int, 0>{}, 0);
+        CP_ACC(t_mfma, tw0);
+        const unsigned long long tf0 = CP_T();
+        (void)tf0;
+        __syncthreads();                                            // every wave has read the weight buffer
+        load_x(cs0 + i);                                            // region registers live only across the flush
+        if (WANT_GX && i >= 1) flush((cs0 + i - 1) * KC);
+        store_x();
+        if (i + 1 < n) dma_a((cs0 + i + 1) * NS, 0);                // lands during the consumption
+        __syncthreads();                                            // region + emptied sums visible
+        CP_ACC(t_flush, tf0);
+      }
       const unsigned long long tw1 = CP_T();
       (void)tw1;
       static_for<0, NS>([&](auto S_) __attribute__((always_inline)) { consume_seg(S_, (cs0 + i) * KC); });
@@ -627,8 +647,10 @@ __global__ __launch_bounds__(256) void dcn_bwd_part_reduce_kernel(const float* _
 }
 
 constexpr int TH_DEFAULT = 8;
+constexpr int TH_WIDE = 12;                // three waves per SIMD, layers with <= 64 output channels
 
 struct D2Plan {
+  int TH;
   int tpr, tpc, ntiles, chunks, NS, slices, chunks_per_slice;
   size_t off_wmax, off_wp, off_slab, off_part, total;
 };
@@ -648,10 +670,20 @@ bool cp_dcn_bwd_data2_supported(const cp_dcn_shape* s) {
   return true;
 }
 
+// CP_DCN_BWD_TH8=1 keeps the 8-row tiles everywhere (A/B timing); read once per process.
+static bool d2_narrow_tiles() {
+  static const bool v = [] { const char* e = getenv("CP_DCN_BWD_TH8"); return e && e[0] == '1'; }();
+  return v;
+}
+
 static D2Plan d2_plan(const cp_dcn_shape* s, bool want_gx, bool want_om) {
   D2Plan p;
+  // 12-row tiles (three waves per SIMD) for the 64-channel-output layers when they still fill the chip twice:
+  // measured 2..7 % faster than 8-row tiles at B >= 4, slower at B = 1 (fewer workgroups)
+  const long long wide_wgs = (long long)((s->W + TW - 1) / TW) * ((s->H + TH_WIDE - 1) / TH_WIDE) * s->B;
+  p.TH = (s->Cout <= 64 && want_gx && wide_wgs >= 1024 && !d2_narrow_tiles()) ? TH_WIDE : TH_DEFAULT;
   p.tpr = (s->W + TW - 1) / TW;
-  p.tpc = (s->H + TH_DEFAULT - 1) / TH_DEFAULT;
+  p.tpc = (s->H + p.TH - 1) / p.TH;
   p.ntiles = p.tpr * p.tpc;
   p.chunks = (s->Cin + KC - 1) / KC;
   p.NS = s->Cout <= 64 ? 1 : (s->Cout <= 128 ? 2 : 4);
@@ -666,7 +698,8 @@ static D2Plan d2_plan(const cp_dcn_shape* s, bool want_gx, bool want_om) {
   p.off_wmax = o; o += 256;
   p.off_wp = o; o += cp_align_up((size_t)p.chunks * p.NS * A_F4 * sizeof(f32x4), 256);
   p.off_slab = o;
-  if (want_gx) o += cp_align_up((size_t)s->B * p.ntiles * s->Cin * Geo<TH_DEFAULT>::RSZ * sizeof(float), 256);
+  if (want_gx)
+    o += cp_align_up((size_t)s->B * p.ntiles * s->Cin * (p.TH + 2 * HALO) * RWD * sizeof(float), 256);
   p.off_part = o;
   if (want_om && p.slices > 1) o += cp_align_up((size_t)p.slices * s->B * 27 * s->H * s->W * sizeof(float), 256);
 #ifdef CP_STAMP
@@ -682,6 +715,13 @@ size_t cp_dcn_bwd_data2_workspace_bytes(const cp_dcn_shape* s) {
 
 template <int CP, bool WANT_GX>
 static void d2_launch(const D2Args& a, const D2Plan& p, int B, hipStream_t st) {
+  if constexpr (CP == 64 && WANT_GX) {
+    if (p.TH == TH_WIDE) {
+      hipLaunchKernelGGL((dcn_bwd_data2_kernel<64, TH_WIDE, true>), dim3(p.ntiles, B, p.slices), dim3(TH_WIDE * 64), 0,
+                         st, a);
+      return;
+    }
+  }
   hipLaunchKernelGGL((dcn_bwd_data2_kernel<CP, TH_DEFAULT, WANT_GX>), dim3(p.ntiles, B, p.slices),
                      dim3(TH_DEFAULT * 64), 0, st, a);
 }
@@ -733,10 +773,10 @@ int cp_dcn_bwd_data2(const cp_dcn_shape* s, const float* x, const float* offset,
     const dim3 grid((per_row + 63) / 64, s->H, (s->B * s->Cin + 3) / 4);
     if (vec)
       hipLaunchKernelGGL(dcn_bwd_gx_reduce_kernel<true>, grid, dim3(256), 0, st, a.slab, grad_x, s->B * s->Cin, s->Cin,
-                         s->H, s->W, p.tpr, p.tpc, TH_DEFAULT);
+                         s->H, s->W, p.tpr, p.tpc, p.TH);
     else
       hipLaunchKernelGGL(dcn_bwd_gx_reduce_kernel<false>, grid, dim3(256), 0, st, a.slab, grad_x, s->B * s->Cin, s->Cin,
-                         s->H, s->W, p.tpr, p.tpc, TH_DEFAULT);
+                         s->H, s->W, p.tpr, p.tpc, p.TH);
   } else {
     if (p.NS == 1) d2_launch<64, false>(a, p, s->B, st);
     else if (p.NS == 2) d2_launch<128, false>(a, p, s->B, st);
