@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libcenterpoly_hip.so")
 
 CP_OK = 0
 REP = {"cartesian": 0, "polar": 1, "polar_fixed": 2}
-L1_PLAIN, L1_POLAR, L1_POLAR_FIXED, L1_RELU20 = 0, 1, 2, 3
+L1_PLAIN, L1_POLAR, L1_POLAR_FIXED, L1_RELU20, L1_SMOOTH = 0, 1, 2, 3, 4
 DCN_CONTRACTION = {"f32": 0, "bf16x3": 1}
 
 
@@ -77,6 +77,9 @@ _SIGNATURES = {
     "cp_sigmoid_focal_backward": (c_int32, [_P, _P, c_int64, _P, _P, _P, _P]),
     "cp_gather_l1_forward": (c_int32, [_P, _P, _P, _P, _P] + [c_int32] * 6 + [c_float, _P, _P]),
     "cp_gather_l1_backward": (c_int32, [_P, _P, _P, _P, _P] + [c_int32] * 6 + [c_float, _P, _P, _P]),
+    "cp_mse_workspace_bytes": (c_size_t, []),
+    "cp_mse_forward": (c_int32, [_P, _P, c_int64, _P, _P, c_size_t, _P]),
+    "cp_mse_backward": (c_int32, [_P, _P, c_int64, _P, _P, _P]),
     "cp_poly_iou_order_workspace_bytes": (c_size_t, [c_int32] * 3),
     "cp_poly_iou_order_forward": (c_int32, [_P, _P, _P, _P] + [c_int32] * 6 + [_P, _P, _P, _P,
                                                                                c_size_t, _P]),

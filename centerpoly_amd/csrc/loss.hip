@@ -182,6 +182,10 @@ __device__ __forceinline__ float gl1_term(int mode, int d, float p, float t) {
       const float a = fabsf(diff);
       return a >= 20.f ? a : 0.f;
     }
+    case CP_L1_SMOOTH: {                     // smooth_l1 (beta 1) of RegLoss / _reg_loss, losses.py:201-216
+      const float a = fabsf(diff);
+      return a < 1.f ? 0.5f * diff * diff : a - 0.5f;
+    }
     default:
       return fabsf(diff);
   }
@@ -197,6 +201,8 @@ __device__ __forceinline__ float gl1_dterm(int mode, int d, float p, float t) {
       return (d & 1) ? 0.f : sgn;
     case CP_L1_RELU20:
       return fabsf(diff) >= 20.f ? sgn : 0.f;
+    case CP_L1_SMOOTH:
+      return fabsf(diff) < 1.f ? diff : sgn;
     default:
       return sgn;
   }
@@ -235,7 +241,8 @@ __global__ __launch_bounds__(1024) void gather_l1_fwd_kernel(GatherArgs a, float
       t += red[w];
       c += cnt_red[w];
     }
-    const float denom = (float)((long long)c * a.D) + a.eps;
+    // RegL1Loss / PolyLoss divide by the EXPANDED mask sum (objects x D), RegLoss by the object count
+    const float denom = (float)(a.mode == CP_L1_SMOOTH ? (long long)c : (long long)c * a.D) + a.eps;
     loss_out[0] = (float)t / denom;
   }
 }
@@ -252,7 +259,7 @@ __global__ __launch_bounds__(256) void gather_l1_bwd_kernel(GatherArgs a, const 
   for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off, 64);
   if ((threadIdx.x & 63) == 0) atomicAdd(&cnt_sh, c);
   __syncthreads();
-  const float denom = (float)((long long)cnt_sh * a.D) + a.eps;
+  const float denom = (float)(a.mode == CP_L1_SMOOTH ? (long long)cnt_sh : (long long)cnt_sh * a.D) + a.eps;
   const float g = grad_loss[0] / denom;
   const long long total = (long long)BM * a.D;
   for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < total;
@@ -307,7 +314,7 @@ static int fill_gather(GatherArgs& a, const float* feat, const int64_t* ind, con
                        int32_t H, int32_t W, int32_t M, int32_t mode, float eps) {
   CP_CHECK_ARG(feat && ind && mask && target);
   CP_CHECK_ARG(B > 0 && D > 0 && H > 0 && W > 0 && M > 0);
-  CP_CHECK_ARG(mode >= CP_L1_PLAIN && mode <= CP_L1_RELU20);
+  CP_CHECK_ARG(mode >= CP_L1_PLAIN && mode <= CP_L1_SMOOTH);
   if ((long long)H * W >= (1ll << 31) || (long long)B * M >= (1ll << 24)) return CP_EUNSUPPORTED;
   a.feat = feat; a.ind = (const long long*)ind; a.mask = mask; a.target = target;
   a.pred_add = pred_add; a.B = B; a.D = D; a.HW = H * W; a.M = M; a.mode = mode; a.eps = eps;
@@ -341,5 +348,69 @@ extern "C" int cp_gather_l1_backward(const float* feat, const int64_t* ind, cons
   if (nb > 1024) nb = 1024;
   hipLaunchKernelGGL(gather_l1_bwd_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, a,
                      grad_loss, grad_feat);
+  return cp_launch_status();
+}
+
+
+// ------------------------------------------------------------------ MSE heat-map loss ---
+// `--mse_loss`: crit = torch.nn.MSELoss() on the RAW heat-map head (no sigmoid), trains/polydet.py:23,44-46,84:
+// loss = mean((x - gt)^2).  One streaming pass each way; double block partials, fixed-order final sum.
+namespace {
+constexpr int MSE_BLOCKS = 1024;
+
+__global__ __launch_bounds__(256) void mse_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gt,
+                                                      long long n, double* __restrict__ part) {
+  double s = 0.0;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const float d = x[i] - gt[i];
+    s += (double)(d * d);
+  }
+  s = cp_wave_sum_d(s);
+  __shared__ double red[4];
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ __launch_bounds__(256) void mse_final_kernel(const double* __restrict__ part, int nparts, long long n,
+                                                        float* __restrict__ loss) {
+  double s = 0.0;
+  for (int i = threadIdx.x; i < nparts; i += 256) s += part[i];
+  s = cp_wave_sum_d(s);
+  __shared__ double red[4];
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) loss[0] = (float)((red[0] + red[1] + red[2] + red[3]) / (double)n);
+}
+
+__global__ __launch_bounds__(256) void mse_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gt,
+                                                      long long n, const float* __restrict__ grad_loss,
+                                                      float* __restrict__ grad) {
+  const float g = 2.f * grad_loss[0] / (float)n;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+    grad[i] = g * (x[i] - gt[i]);
+}
+}  // namespace
+
+extern "C" size_t cp_mse_workspace_bytes(void) { return MSE_BLOCKS * sizeof(double); }
+
+extern "C" int cp_mse_forward(const float* x, const float* gt, int64_t n, float* loss_out, void* workspace,
+                              size_t workspace_bytes, void* stream) {
+  CP_CHECK_ARG(x && gt && loss_out && n > 0 && workspace && workspace_bytes >= cp_mse_workspace_bytes());
+  long long nb = (n + 255) / 256;
+  if (nb > MSE_BLOCKS) nb = MSE_BLOCKS;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(mse_fwd_kernel, dim3((unsigned)nb), dim3(256), 0, st, x, gt, (long long)n, (double*)workspace);
+  hipLaunchKernelGGL(mse_final_kernel, dim3(1), dim3(256), 0, st, (const double*)workspace, (int)nb, (long long)n, loss_out);
+  return cp_launch_status();
+}
+
+extern "C" int cp_mse_backward(const float* x, const float* gt, int64_t n, const float* grad_loss, float* grad_x,
+                               void* stream) {
+  CP_CHECK_ARG(x && gt && grad_loss && grad_x && n > 0);
+  long long nb = (n + 255) / 256;
+  if (nb > 4096) nb = 4096;
+  hipLaunchKernelGGL(mse_bwd_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, x, gt, (long long)n,
+                     grad_loss, grad_x);
   return cp_launch_status();
 }

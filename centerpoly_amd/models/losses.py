@@ -126,6 +126,43 @@ class RegL1Loss(nn.Module):
         return _GatherL1.apply(output, mask, ind, target, None, _C.L1_PLAIN, 1e-4)
 
 
+class RegLoss(nn.Module):
+    """losses.py:801-815 (`--reg_loss sl1`): smooth-L1 on the gathered rows, divided by the number of
+    masked objects + 1e-4 (not by objects x D)."""
+
+    def forward(self, output, mask, ind, target):
+        return _GatherL1.apply(output, mask, ind, target, None, _C.L1_SMOOTH, 1e-4)
+
+
+class _Mse(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gt):
+        L = _C.lib()
+        x, gt = _f32c(x), _f32c(gt)
+        loss = torch.empty((), dtype=torch.float32, device=x.device)
+        nws = L.cp_mse_workspace_bytes()
+        ws = _C.workspace(nws, x.device)
+        _C.check(L.cp_mse_forward(_C.ptr(x), _C.ptr(gt), x.numel(), _C.ptr(loss), _C.ptr(ws), nws, _C.stream()),
+                 "cp_mse_forward")
+        ctx.save_for_backward(x, gt)
+        return loss
+
+    @staticmethod
+    def backward(ctx, grad_loss):
+        x, gt = ctx.saved_tensors
+        g = torch.empty_like(x)
+        _C.check(_C.lib().cp_mse_backward(_C.ptr(x), _C.ptr(gt), x.numel(), _C.ptr(_f32c(grad_loss.reshape(1))),
+                                          _C.ptr(g), _C.stream()), "cp_mse_backward")
+        return g, None
+
+
+class MSELoss(nn.Module):
+    """`--mse_loss`: torch.nn.MSELoss() on the raw heat-map head (trains/polydet.py:23)."""
+
+    def forward(self, out, target):
+        return _Mse.apply(out, target)
+
+
 # ------------------------------------------------------- polygon losses -----
 
 class _PolyIouOrder(torch.autograd.Function):

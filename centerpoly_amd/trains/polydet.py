@@ -8,11 +8,11 @@ cat_spec_poly, dense_poly; reference :49-70,103-111, all default off) raise.
 import torch
 
 from ..models.decode import polydet_decode
-from ..models.losses import FocalLoss, PolyLoss, RegL1Loss, sigmoid_focal_loss
+from ..models.losses import FocalLoss, MSELoss, PolyLoss, RegL1Loss, RegLoss, sigmoid_focal_loss
 from ..utils.post_process import polydet_post_process
 from .base_trainer import BaseTrainer
 
-_UNSUPPORTED = ("mse_loss", "eval_oracle_hm", "eval_oracle_border_hm", "eval_oracle_offset",
+_UNSUPPORTED = ("eval_oracle_hm", "eval_oracle_border_hm", "eval_oracle_offset",
                 "eval_oracle_poly", "eval_oracle_pseudo_depth", "cat_spec_poly", "dense_poly")
 
 
@@ -22,10 +22,11 @@ class PolydetLoss(torch.nn.Module):
         for flag in _UNSUPPORTED:
             if getattr(opt, flag, False):
                 raise NotImplementedError("--%s is outside the accelerated polydet path" % flag)
-        if getattr(opt, "reg_loss", "l1") != "l1":
-            raise NotImplementedError("only --reg_loss l1 is accelerated")
-        self.crit = FocalLoss()
-        self.crit_reg = RegL1Loss()
+        if getattr(opt, "reg_loss", "l1") not in ("l1", "sl1"):
+            raise NotImplementedError("--reg_loss must be l1 or sl1 (the reference leaves crit_reg None otherwise)")
+        self.mse = bool(getattr(opt, "mse_loss", False))
+        self.crit = MSELoss() if self.mse else FocalLoss()
+        self.crit_reg = RegL1Loss() if getattr(opt, "reg_loss", "l1") == "l1" else RegLoss()
         self.crit_poly = PolyLoss(opt)
         self.opt = opt
 
@@ -37,8 +38,10 @@ class PolydetLoss(torch.nn.Module):
             depth_loss = depth_loss + self.crit_reg(
                 output["pseudo_depth"], batch["reg_mask"], batch["ind"],
                 batch["pseudo_depth"]) / opt.num_stacks
-            # _sigmoid + FocalLoss fused; output['hm'] becomes the activated map in place
-            hm_l, output["hm"] = sigmoid_focal_loss(output["hm"], batch["hm"])
+            if self.mse:                     # --mse_loss: MSE on the raw head, no activation (:44-46,84)
+                hm_l = self.crit(output["hm"], batch["hm"])
+            else:                            # _sigmoid + FocalLoss fused; output['hm'] becomes the activated map
+                hm_l, output["hm"] = sigmoid_focal_loss(output["hm"], batch["hm"])
             hm_loss = hm_loss + hm_l / opt.num_stacks
             r = self.crit_poly(output["poly"], batch["reg_mask"], batch["ind"], batch["poly"],
                                freq_mask=batch.get("freq_mask"), peak=batch.get("peak"),

@@ -73,7 +73,8 @@ enum {
   CP_L1_PLAIN = 0,       /* RegL1Loss / PolyLoss cartesian: sum |p*m - t*m|            */
   CP_L1_POLAR = 1,       /* PolyLoss polar: L1 on even slots + sum(1-cos) on odd slots */
   CP_L1_POLAR_FIXED = 2, /* PolyLoss polar_fixed: L1 on even (radius) slots only       */
-  CP_L1_RELU20 = 3       /* PolyLoss 'relu': |p-t| kept only where >= 20               */
+  CP_L1_RELU20 = 3,      /* PolyLoss 'relu': |p-t| kept only where >= 20               */
+  CP_L1_SMOOTH = 4       /* RegLoss (--reg_loss sl1): smooth_l1, divided by sum(mask) + eps (not x D) */
 };
 
 int cp_abi_version(void);
@@ -319,6 +320,14 @@ int cp_gather_l1_backward(const float* feat, const int64_t* ind, const uint8_t* 
                           const float* target, const float* pred_add, int32_t B, int32_t D,
                           int32_t H, int32_t W, int32_t M, int32_t mode, float eps,
                           const float* grad_loss, float* grad_feat, void* stream);
+
+/* `--mse_loss` (src/lib/trains/polydet.py:23,44-46,84): torch.nn.MSELoss() between the RAW heat-map head (no
+ * sigmoid) and the target, loss = mean((x - gt)^2); backward grad_x = 2 (x - gt) / n * grad_loss[0]. */
+size_t cp_mse_workspace_bytes(void);
+int cp_mse_forward(const float* x, const float* gt, int64_t n, float* loss_out, void* workspace,
+                   size_t workspace_bytes, void* stream);
+int cp_mse_backward(const float* x, const float* gt, int64_t n, const float* grad_loss, float* grad_x,
+                    void* stream);
 
 /* ----------------------------------- polygon IoU (Weiler-Atherton) + order --
  * feat = polygon head [B,2N,H,W]; per masked object the literal reference

@@ -56,6 +56,15 @@ def reg_l1_loss(output, mask, ind, target):
     return loss / (m.sum() + 1e-4)
 
 
+def reg_sl1_loss(output, mask, ind, target):
+    """RegLoss / _reg_loss (losses.py:201-216, 801-815), `--reg_loss sl1`."""
+    pred = gather_feat(output, ind)
+    num = mask.float().sum()
+    m = mask.unsqueeze(2).expand_as(target).float()
+    loss = F.smooth_l1_loss(pred * m, target * m, reduction="sum")
+    return loss / (num + 1e-4)
+
+
 # ----------------------------------------------------------------------------
 # Weiler-Atherton clip, literal (losses.py:373-628)
 # ----------------------------------------------------------------------------
@@ -281,16 +290,20 @@ def poly_loss(output, mask, ind, target, poly_loss="l1", rep="cartesian", poly_o
 
 def polydet_loss(outputs, batch, *, num_stacks=1, poly_loss_kind="l1", rep="cartesian",
                  poly_order=False, hm_weight=1.0, off_weight=1.0, poly_weight=1.0,
-                 depth_weight=0.1, reg_offset=True):
+                 depth_weight=0.1, reg_offset=True, reg_loss="l1", mse_loss=False):
     """trains/polydet.py:38-162 (default switches).  `outputs` = list of dicts of
     RAW head outputs; returns (loss, stats dict) and leaves outputs untouched."""
     hm_l = off_l = poly_l = depth_l = order_l = 0
     for s in range(num_stacks):
         o = outputs[s]
-        hm = sigmoid_clamp(o["hm"])
-        depth_l = depth_l + reg_l1_loss(o["pseudo_depth"], batch["reg_mask"], batch["ind"],
-                                        batch["pseudo_depth"]) / num_stacks
-        hm_l = hm_l + neg_loss(hm, batch["hm"]) / num_stacks
+        reg_crit = reg_l1_loss if reg_loss == "l1" else reg_sl1_loss
+        depth_l = depth_l + reg_crit(o["pseudo_depth"], batch["reg_mask"], batch["ind"],
+                                     batch["pseudo_depth"]) / num_stacks
+        if mse_loss:                         # trains/polydet.py:23,44-46: MSELoss on the raw head
+            hm_l = hm_l + F.mse_loss(o["hm"], batch["hm"]) / num_stacks
+        else:
+            hm = sigmoid_clamp(o["hm"])
+            hm_l = hm_l + neg_loss(hm, batch["hm"]) / num_stacks
         r = poly_loss(o["poly"], batch["reg_mask"], batch["ind"], batch["poly"],
                       poly_loss_kind, rep, poly_order)
         if poly_order:
@@ -299,8 +312,8 @@ def polydet_loss(outputs, batch, *, num_stacks=1, poly_loss_kind="l1", rep="cart
         else:
             poly_l = poly_l + r / num_stacks
         if reg_offset and off_weight > 0:
-            off_l = off_l + reg_l1_loss(o["reg"], batch["reg_mask"], batch["ind"],
-                                        batch["reg"]) / num_stacks
+            off_l = off_l + reg_crit(o["reg"], batch["reg_mask"], batch["ind"],
+                                     batch["reg"]) / num_stacks
     if poly_order:
         loss = hm_weight * hm_l + off_weight * off_l + poly_weight * (poly_l + order_l) \
             + depth_weight * depth_l

@@ -69,7 +69,7 @@ def _import_reference():
 
 _import_reference()
 from models.decode import _nms, _topk, polydet_decode            # noqa: E402
-from models.losses import FocalLoss, RegL1Loss, PolyLoss, WeilPolygonClipper, area  # noqa: E402
+from models.losses import FocalLoss, RegL1Loss, RegLoss, PolyLoss, WeilPolygonClipper, area  # noqa: E402
 from models.utils import _sigmoid                                 # noqa: E402
 from models.networks.large_hourglass import HourglassNet          # noqa: E402
 from models.networks.pose_dla_dcn import DLASeg                   # noqa: E402
@@ -136,6 +136,17 @@ def gen_losses():
         l = RegL1Loss()(o, T(batch["reg_mask"]), T(batch["ind"]), T(batch[key]))
         l.backward()
         save("loss_regl1_" + key, loss=l.detach().numpy(), grad=o.grad.numpy())
+    # --reg_loss sl1 (RegLoss) and --mse_loss (torch MSELoss on the raw head), trains/polydet.py:23-25
+    batch, out = loss_batch("base", 2, 32, 48, 16, "cartesian")
+    for key in ("reg", "pseudo_depth"):
+        o = T(out[key] * 3.0).requires_grad_(True)          # |diff| on both sides of the smooth-L1 knee
+        l = RegLoss()(o, T(batch["reg_mask"]), T(batch["ind"]), T(batch[key]))
+        l.backward()
+        save("loss_regsl1_" + key, loss=l.detach().numpy(), grad=o.grad.numpy())
+    xm = T(out["hm"]).requires_grad_(True)
+    lm = torch.nn.MSELoss()(xm, T(batch["hm"]))
+    lm.backward()
+    save("loss_mse", loss=lm.detach().numpy(), grad=xm.grad.numpy())
     for name, B, h, w, N, rep, pl, order in POLY_CASES:
         batch, out = loss_batch(name, B, h, w, N, rep)
         o = T(out["poly"]).requires_grad_(True)

@@ -160,6 +160,40 @@ def test_regl1_vs_golden(key, golden):
     np.testing.assert_allclose(o.grad.cpu().numpy(), gold["grad"], rtol=1e-5, atol=1e-9)
 
 
+@pytest.mark.parametrize("key", ["reg", "pseudo_depth"])
+def test_regsl1_vs_golden(key, golden):
+    """--reg_loss sl1: cp_gather_l1 in smooth-L1 mode against the reference's RegLoss."""
+    from centerpoly_amd.models.losses import RegLoss
+    batch, out = cases.loss_batch("base", 2, 32, 48, 16, "cartesian")
+    gold = golden("loss_regsl1_" + key)
+    o = g(out[key] * 3.0).requires_grad_(True)
+    l = RegLoss()(o, g(batch["reg_mask"]), g(batch["ind"]), g(batch[key]))
+    l.backward()
+    np.testing.assert_allclose(l.item(), gold["loss"], rtol=1e-5)
+    np.testing.assert_allclose(o.grad.cpu().numpy(), gold["grad"], rtol=1e-5, atol=1e-9)
+
+
+def test_mse_heat_loss_vs_golden_and_in_polydet_loss(golden):
+    """--mse_loss: cp_mse_forward/backward against torch MSELoss recorded from the reference environment, and
+    PolydetLoss with --mse_loss --reg_loss sl1 against the oracle."""
+    from centerpoly_amd.models.losses import MSELoss
+    from centerpoly_amd.trains.polydet import PolydetLoss
+    batch, out = cases.loss_batch("base", 2, 32, 48, 16, "cartesian")
+    gold = golden("loss_mse")
+    x = g(out["hm"]).requires_grad_(True)
+    l = MSELoss()(x, g(batch["hm"]))
+    l.backward()
+    np.testing.assert_allclose(l.item(), gold["loss"], rtol=1e-5)
+    np.testing.assert_allclose(x.grad.cpu().numpy(), gold["grad"], rtol=1e-5, atol=1e-10)
+    opt = _Opt(num_stacks=1, poly_loss="l1", rep="cartesian", poly_order=False, hm_weight=1.0, off_weight=1.0,
+               poly_weight=1.0, depth_weight=0.1, reg_offset=True, reg_loss="sl1", mse_loss=True, task="polydet")
+    loss, stats = PolydetLoss(opt)([{k: g(v) for k, v in out.items()}], {k: g(v) for k, v in batch.items()})
+    ref, rstats = olos.polydet_loss([{k: T(v) for k, v in out.items()}], {k: T(v) for k, v in batch.items()},
+                                    poly_loss_kind="l1", rep="cartesian", reg_loss="sl1", mse_loss=True)
+    for k in rstats:
+        np.testing.assert_allclose(float(stats[k]), float(rstats[k]), rtol=1e-4, atol=1e-6, err_msg=k)
+
+
 class _Opt:
     def __init__(self, **kw):
         self.__dict__.update(kw)

@@ -78,6 +78,24 @@ def test_regl1_matches_reference(key, golden):
     np.testing.assert_allclose(o.grad.numpy(), g["grad"], rtol=1e-6, atol=1e-9)
 
 
+@pytest.mark.parametrize("key", ["reg", "pseudo_depth"])
+def test_regsl1_and_mse_match_reference(key, golden):
+    """`--reg_loss sl1` (RegLoss, losses.py:801-815) and `--mse_loss` (torch MSELoss on the raw head,
+    trains/polydet.py:23) against values and gradients recorded from the reference's own classes."""
+    batch, out = cases.loss_batch("base", 2, 32, 48, 16, "cartesian")
+    g = golden("loss_regsl1_" + key)
+    o = T(out[key] * 3.0).requires_grad_(True)
+    l = olos.reg_sl1_loss(o, T(batch["reg_mask"]), T(batch["ind"]), T(batch[key]))
+    l.backward()
+    np.testing.assert_allclose(l.item(), g["loss"], rtol=1e-6)
+    np.testing.assert_allclose(o.grad.numpy(), g["grad"], rtol=1e-6, atol=1e-9)
+    gm = golden("loss_mse")
+    x = T(out["hm"]).requires_grad_(True)
+    stats = olos.polydet_loss([{k: (x if k == "hm" else T(v)) for k, v in out.items()}],
+                              {k: T(v) for k, v in batch.items()}, mse_loss=True)[1]
+    np.testing.assert_allclose(stats["hm_l"].item(), gm["loss"], rtol=1e-6)
+
+
 @pytest.mark.parametrize("case", cases.POLY_CASES, ids=lambda c: c[0])
 def test_polyloss_matches_reference(case, golden):
     name, B, h, w, N, rep, pl, order = case
