@@ -134,6 +134,46 @@ __global__ __launch_bounds__(256) void dcn_bwd_wperm_kernel(const float* __restr
   if ((threadIdx.x & 63) == 0 && mx > 0.f) atomicMax(wmax_bits, __float_as_uint(mx));   // positive floats order as uints
 }
 
+// Split-bf16 form of the same stage (contraction on the bf16 matrix cores as three products of bf16 halves,
+// w = wh + wl, wh = bf16(w), wl = bf16(w - wh)): per (chunk, slab, tap) two k-steps of 32 output channels, each
+// a hi and a lo fragment of 8 bf16 per lane -- the A-operand layout of v_mfma_f32_16x16x32_bf16 (row = lane & 15,
+// k = 8 (lane >> 4) + j).  Same 36 864 bytes per stage as the f32 form, so the LDS-DMA path is shared.
+// wpb[(((chunk*NS + slab)*9 + t)*2 + k32)*2 + hl][lane][j] = half(hl) of W[co = slab*64 + 32 k32 + 8 (lane >> 4) + j]
+//                                                                     [ci = chunk*16 + (lane & 15)][t]
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__global__ __launch_bounds__(256) void dcn_bwd_wperm_bf16_kernel(const float* __restrict__ w, bf16x8* __restrict__ wpb,
+                                                                 unsigned* __restrict__ wmax_bits, int Cin, int Cout,
+                                                                 int NS, int total_frag) {
+  const int e = blockIdx.x * 256 + threadIdx.x;                      // one (hi or lo) fragment of 8 values
+  float mx = 0.f;
+  if (e < total_frag) {
+    const int lane = e & 63;
+    int r = e >> 6;
+    const int hl = r & 1;
+    r >>= 1;
+    const int k32 = r & 1;
+    r >>= 1;
+    const int t = r % TAPS;
+    r /= TAPS;
+    const int slab = r % NS, chunk = r / NS;
+    const int ci = chunk * KC + (lane & 15);
+    bf16x8 out;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int co = slab * 64 + 32 * k32 + 8 * (lane >> 4) + j;
+      const float v = (co < Cout && ci < Cin) ? w[((long long)co * Cin + ci) * TAPS + t] : 0.f;
+      mx = fmaxf(mx, fabsf(v));
+      const __bf16 h = (__bf16)v;
+      out[j] = hl ? (__bf16)(v - (float)h) : h;
+    }
+    wpb[e] = out;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  if ((threadIdx.x & 63) == 0 && mx > 0.f) atomicMax(wmax_bits, __float_as_uint(mx));
+}
+
 // ---- main kernel ---------------------------------------------------------------------------------
 // Schedule: every wave runs the matrix phase of a chunk (NS stages, one 64-channel weight slab each,
 // published by LDS-DMA into a double buffer behind ONE barrier per stage), then its consumption.  A
@@ -141,7 +181,7 @@ __global__ __launch_bounds__(256) void dcn_bwd_wperm_kernel(const float* __restr
 // measured equal within 2 %: on gfx950 the f32 MFMA executes on the SIMD's vector ALUs
 // (SQ_VALU_MFMA_COEXEC_CYCLES = 0 in every profile of this kernel), so the two phases of one SIMD never
 // overlap whichever waves run them.
-template <int CP, int TH, bool WANT_GX>
+template <int CP, int TH, bool WANT_GX, bool BF>
 __global__ __launch_bounds__(TH * 64, TH / 4) void dcn_bwd_data2_kernel(D2Args a) {
   using G = Geo<TH>;
   constexpr int RSZ = G::RSZ, RSZP = G::RSZP, RH = G::RH, NPX = G::NPX, NTHR = G::NTHR;
@@ -222,20 +262,39 @@ __global__ __launch_bounds__(TH * 64, TH / 4) void dcn_bwd_data2_kernel(D2Args a
   const float* gob = a.go + (long long)b * a.Cout * HW;
   const __amdgpu_buffer_rsrc_t rs_go = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(gob), 0, (int)((unsigned)a.Cout * (unsigned)HW * 4u), 0x00020000);
-  float breg[NB];
-  {
+  // f32 form: breg[q] = go[co = 4 q + g]; split-bf16 form: per slab and k-step of 32 channels the hi / lo halves of
+  // go[co = 64 slab + 32 k32 + 8 g + j], j = 0..7 (B-operand layout of the 16x16x32 instruction) -- converted ONCE
+  // per tile; the weights are split by the prologue kernel, so the matrix phase carries no conversion at all.
+  float breg[BF ? 1 : NB];
+  bf16x8 bh[BF ? NS * 2 : 1], bl[BF ? NS * 2 : 1];
+  float l1_lane = 0.f;
+  if constexpr (!BF) {
     const unsigned gbase = p_ok ? ((unsigned)g * (unsigned)HW + (unsigned)p) * 4u : OOB;
     const unsigned gstep = p_ok ? (unsigned)HW * 16u : 0u;          // 4 output channels
 #pragma unroll
-    for (int q = 0; q < NB; ++q)                                    // rows past Cout read 0
+    for (int q = 0; q < NB; ++q) {                                  // rows past Cout read 0
       breg[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_go, gbase + (unsigned)q * gstep, 0, 0));
+      l1_lane += fabsf(breg[q]);
+    }
+  } else {
+    const unsigned gstep = p_ok ? (unsigned)HW * 4u : 0u;           // 1 output channel
+#pragma unroll
+    for (int kk = 0; kk < NS * 2; ++kk) {
+      const unsigned gbase = p_ok ? ((unsigned)(32 * kk + 8 * g) * (unsigned)HW + (unsigned)p) * 4u : OOB;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_go, gbase + (unsigned)j * gstep, 0, 0));
+        l1_lane += fabsf(v);
+        const __bf16 h = (__bf16)v;
+        bh[kk][j] = h;
+        bl[kk][j] = (__bf16)(v - (float)h);
+      }
+    }
   }
   // fixed-point scale from a bound of |gcol|: max over the tile's pixels of sum_co |go| times max |W|
   double fx_scale = 0.0, fx_inv = 0.0;
   if (WANT_GX) {
-    float l1 = 0.f;
-#pragma unroll
-    for (int q = 0; q < NB; ++q) l1 += fabsf(breg[q]);
+    float l1 = l1_lane;
     l1 += __shfl_xor(l1, 16, 64);
     l1 += __shfl_xor(l1, 32, 64);
 #pragma unroll
@@ -355,19 +414,34 @@ __global__ __launch_bounds__(TH * 64, TH / 4) void dcn_bwd_data2_kernel(D2Args a
 
   auto mfma_slab = [&](auto S_, int buf) __attribute__((always_inline)) {
     constexpr int s = decltype(S_)::value;
+    if constexpr (BF) {
+      const bf16x8* Ab = reinterpret_cast<const bf16x8*>(&Abuf[buf][0]);      // [tap][k32][hl][lane]
 #pragma unroll
-    for (int ks4 = 0; ks4 < 4; ++ks4) {
+      for (int k32 = 0; k32 < 2; ++k32) {
 #pragma unroll
-      for (int t0 = 0; t0 < TAPS; t0 += 3) {
-        f32x4 af[3];
+        for (int t = 0; t < TAPS; ++t) {
+          const bf16x8 ah = Ab[((t * 2 + k32) * 2 + 0) * 64 + lane];
+          const bf16x8 al = Ab[((t * 2 + k32) * 2 + 1) * 64 + lane];
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[s * 2 + k32], acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[s * 2 + k32], acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[s * 2 + k32], acc[t], 0, 0, 0);
+        }
+      }
+    } else {
 #pragma unroll
-        for (int u = 0; u < 3; ++u) af[u] = Abuf[buf][((t0 + u) * 4 + ks4) * 64 + lane];
+      for (int ks4 = 0; ks4 < 4; ++ks4) {
 #pragma unroll
-        for (int u = 0; u < 3; ++u) {
-          acc[t0 + u] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[u].x, breg[s * 16 + ks4 * 4 + 0], acc[t0 + u], 0, 0, 0);
-          acc[t0 + u] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[u].y, breg[s * 16 + ks4 * 4 + 1], acc[t0 + u], 0, 0, 0);
-          acc[t0 + u] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[u].z, breg[s * 16 + ks4 * 4 + 2], acc[t0 + u], 0, 0, 0);
-          acc[t0 + u] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[u].w, breg[s * 16 + ks4 * 4 + 3], acc[t0 + u], 0, 0, 0);
+        for (int t0 = 0; t0 < TAPS; t0 += 3) {
+          f32x4 af[3];
+#pragma unroll
+          for (int u = 0; u < 3; ++u) af[u] = Abuf[buf][((t0 + u) * 4 + ks4) * 64 + lane];
+#pragma unroll
+          for (int u = 0; u < 3; ++u) {
+            acc[t0 + u] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[u].x, breg[s * 16 + ks4 * 4 + 0], acc[t0 + u], 0, 0, 0);
+            acc[t0 + u] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[u].y, breg[s * 16 + ks4 * 4 + 1], acc[t0 + u], 0, 0, 0);
+            acc[t0 + u] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[u].z, breg[s * 16 + ks4 * 4 + 2], acc[t0 + u], 0, 0, 0);
+            acc[t0 + u] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[u].w, breg[s * 16 + ks4 * 4 + 3], acc[t0 + u], 0, 0, 0);
+          }
         }
       }
     }
@@ -713,17 +787,31 @@ size_t cp_dcn_bwd_data2_workspace_bytes(const cp_dcn_shape* s) {
   return cp_dcn_bwd_data2_supported(s) ? d2_plan(s, true, true).total : 0;
 }
 
-template <int CP, bool WANT_GX>
-static void d2_launch(const D2Args& a, const D2Plan& p, int B, hipStream_t st) {
+// Contraction of the grad columns: split-bf16 x3 on the bf16 matrix cores (default) or the exact f32 MFMA chain
+// (CP_DCN_BWD_F32=1; read once per process).  The f32-input MFMA executes on the SIMD's vector ALUs and serialises
+// with the consumption's VALU work; the bf16 cores run beside it.  |error| of a grad column <= 3 * 2^-17 * sum|w go|.
+static bool d2_exact_f32() {
+  static const bool v = [] { const char* e = getenv("CP_DCN_BWD_F32"); return e && e[0] == '1'; }();
+  return v;
+}
+
+template <int CP, bool WANT_GX, bool BF>
+static void d2_launch_bf(const D2Args& a, const D2Plan& p, int B, hipStream_t st) {
   if constexpr (CP == 64 && WANT_GX) {
     if (p.TH == TH_WIDE) {
-      hipLaunchKernelGGL((dcn_bwd_data2_kernel<64, TH_WIDE, true>), dim3(p.ntiles, B, p.slices), dim3(TH_WIDE * 64), 0,
-                         st, a);
+      hipLaunchKernelGGL((dcn_bwd_data2_kernel<64, TH_WIDE, true, BF>), dim3(p.ntiles, B, p.slices),
+                         dim3(TH_WIDE * 64), 0, st, a);
       return;
     }
   }
-  hipLaunchKernelGGL((dcn_bwd_data2_kernel<CP, TH_DEFAULT, WANT_GX>), dim3(p.ntiles, B, p.slices),
+  hipLaunchKernelGGL((dcn_bwd_data2_kernel<CP, TH_DEFAULT, WANT_GX, BF>), dim3(p.ntiles, B, p.slices),
                      dim3(TH_DEFAULT * 64), 0, st, a);
+}
+
+template <int CP, bool WANT_GX>
+static void d2_launch(const D2Args& a, const D2Plan& p, int B, hipStream_t st) {
+  if (d2_exact_f32()) d2_launch_bf<CP, WANT_GX, false>(a, p, B, st);
+  else d2_launch_bf<CP, WANT_GX, true>(a, p, B, st);
 }
 
 // Data gradients of cp_dcn_v2_backward on the caller's workspace.  Returns CP_OK, or CP_EINVAL when
@@ -741,8 +829,12 @@ int cp_dcn_bwd_data2(const cp_dcn_shape* s, const float* x, const float* offset,
   f32x4* wp = (f32x4*)(ws + p.off_wp);
   (void)hipMemsetAsync(wmax_bits, 0, 4, st);
   const int total_f4 = p.chunks * p.NS * A_F4;
-  hipLaunchKernelGGL(dcn_bwd_wperm_kernel, dim3((total_f4 + 255) / 256), dim3(256), 0, st, weight, (float4*)wp, wmax_bits,
-                     s->Cin, s->Cout, p.NS, total_f4);
+  if (d2_exact_f32())
+    hipLaunchKernelGGL(dcn_bwd_wperm_kernel, dim3((total_f4 + 255) / 256), dim3(256), 0, st, weight, (float4*)wp,
+                       wmax_bits, s->Cin, s->Cout, p.NS, total_f4);
+  else                                                     // (a bf16x8 fragment is 16 bytes: same count, same bytes)
+    hipLaunchKernelGGL(dcn_bwd_wperm_bf16_kernel, dim3((total_f4 + 255) / 256), dim3(256), 0, st, weight, (bf16x8*)wp,
+                       wmax_bits, s->Cin, s->Cout, p.NS, total_f4);
   const int HW = s->H * s->W;
   D2Args a;
   a.x = x; a.offset = offset; a.mask = mask; a.go = grad_out; a.wp = wp; a.wmax = (const float*)wmax_bits;

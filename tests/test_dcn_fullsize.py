@@ -117,9 +117,11 @@ def test_batch_split_equality_and_determinism_full_size(shape):
     gw_sum = torch.zeros_like(gw)
     for b in range(B):
         sx, som, sw, _ = _backward(x[b:b + 1].contiguous(), om[b:b + 1].contiguous(), w, go[b:b + 1].contiguous())
-        assert torch.equal(sx[0], gx[b]), "grad_x of image %d depends on the batch" % b
-        # a one-image launch may split the input channels over more workgroups than the batched one
-        # (grid filling): its grad_offset / grad_mask partial sums then meet in another order
+        # a one-image launch may use another tile height and split the input channels over more workgroups
+        # than the batched one (grid filling): the per-tile fixed-point scale and the order in which the
+        # partial sums (grad_x slabs, grad_offset / grad_mask partials) meet then differ in the last bits
+        assert (sx[0] - gx[b]).abs().max().item() <= 2e-6 * gx[b].abs().max().item(), \
+            "grad_x of image %d depends on the batch" % b
         assert (som[0] - gom[b]).abs().max().item() <= 1e-5 * gom[b].abs().max().item(), \
             "grad_offset/mask of image %d depends on the batch" % b
         gw_sum += sw
