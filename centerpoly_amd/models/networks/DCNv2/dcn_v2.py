@@ -16,6 +16,7 @@ import torch.nn as nn
 from torch.nn.modules.utils import _pair
 
 from .... import _C
+from ..conv3x3 import conv3x3_infer, conv_raw
 
 
 def _shape(x, weight, stride, pad, dil, dg):
@@ -130,7 +131,7 @@ def conv_bias(conv, x):
     in-place epilogue and one channel-sum kernel."""
     if x.is_cuda and conv.bias is not None and torch.is_grad_enabled() and x.dtype == torch.float32 \
             and conv.groups == 1:
-        y = F.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation)
+        y = conv_raw(conv, x)
         if y.is_contiguous() and (y.shape[2] * y.shape[3]) % 4 == 0 and y.shape[0] * y.shape[1] <= 65535:
             return _ConvBias.apply(y, conv.bias)
         return y + conv.bias.view(1, -1, 1, 1)
@@ -177,7 +178,10 @@ class DCN(nn.Module):
     def forward_fused(self, x, ep_scale, ep_shift, relu=True):
         """Inference: DCN + per-channel affine (folded BatchNorm, bias included) + ReLU
         in the kernel's epilogue (replaces DeformConv.forward's three passes)."""
-        om = self.conv_offset_mask(x)
+        cm = self.conv_offset_mask
+        om = conv3x3_infer(x, cm, cm.weight, cm.bias, conv=cm)      # split-bf16 MFMA kernel, bias in its epilogue
+        if om is None:
+            om = cm(x)
         return dcn_v2_forward_raw(x.contiguous(), om.contiguous(), self.weight, None, self.stride,
                                   self.padding, self.dilation, self.deformable_groups, ep_scale,
                                   ep_shift, relu, getattr(self, "contraction", "f32"))

@@ -1,0 +1,109 @@
+"""Host side of the split-bf16 MFMA 3x3 convolution (csrc/conv_mfma.hip, include/centerpoly_hip.h
+cp_conv3x3_mfma_*): the dense 3x3 / stride 1 / pad 1 convolutions of the reference's networks
+(src/lib/models/networks/pose_dla_dcn.py BasicBlock :38-66, heads :445-462, DCNv2/dcn_v2.py:137-145
+conv_offset_mask; large_hourglass.py convolution :24-37, residual :55-81), which the reference hands
+to cuDNN.  float32 in and out; forward and input gradient run on the bf16 matrix cores as three
+products of split halves, the weight gradient is the library's.
+
+`conv_raw(conv, x)` is what every training call site uses for "conv without its bias";
+`conv3x3_infer(x, conv, w, bias, residual, relu)` is the inference call with the fused epilogue.
+Shapes the kernel does not take (stride 2, 1x1, 7x7, fewer than 24 input channels, tiny maps) go to the direct
+kernel or the library.  CP_CONV_MFMA=0 turns the kernel off (A/B measurements)."""
+import os
+
+import torch
+import torch.nn.functional as F
+
+from ... import _C
+
+_ENABLED = os.environ.get("CP_CONV_MFMA", "1") != "0"
+MIN_CIN = 24                 # the contraction steps over 32 input channels: fewer would mostly multiply zeros
+MIN_WORKGROUPS = 96          # below this the launch cannot fill the 256 CUs and the library is faster
+
+
+def _workgroups(B, cout, H, W):
+    rows = 16 if cout <= 32 else 8
+    per_wg = 32 if cout <= 32 else 64
+    return B * ((W + 31) // 32) * ((H + rows - 1) // rows) * ((cout + per_wg - 1) // per_wg)
+
+
+def usable_shape(x, cout):
+    """True when a 3x3 / stride 1 / pad 1 convolution of x to `cout` channels is a launch of the MFMA kernel."""
+    if not (_ENABLED and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4):
+        return False
+    B, cin, H, W = x.shape
+    return cin >= MIN_CIN and bool(_C.lib().cp_conv3x3_mfma_supported(cin, cout, H, W)) \
+        and _workgroups(B, cout, H, W) >= MIN_WORKGROUPS
+
+
+def usable(conv, x):
+    """True when conv(x) (without bias) is a launch of the MFMA kernel."""
+    return (conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1)
+            and conv.dilation == (1, 1) and conv.groups == 1 and conv.padding_mode == "zeros"
+            and usable_shape(x, conv.out_channels))
+
+
+def _prepare(weight, cin, cout, transposed):
+    L = _C.lib()
+    wp = torch.empty(L.cp_conv3x3_mfma_weight_bytes(cin, cout), dtype=torch.uint8, device=weight.device)
+    _C.check(L.cp_conv3x3_mfma_prepare(_C.ptr(weight), cin, cout, 1 if transposed else 0, _C.ptr(wp), _C.stream()),
+             "cp_conv3x3_mfma_prepare")
+    return wp
+
+
+def _launch(x, wp, bias, residual, cout, relu):
+    B, cin, H, W = x.shape
+    out = torch.empty((B, cout, H, W), dtype=torch.float32, device=x.device)
+    _C.check(_C.lib().cp_conv3x3_mfma_forward(_C.ptr(x), _C.ptr(wp), _C.ptr(bias), _C.ptr(residual), _C.ptr(out),
+                                              B, cin, H, W, cout, 1 if relu else 0, _C.stream()),
+             "cp_conv3x3_mfma_forward")
+    return out
+
+
+def conv3x3_infer(x, owner, w, bias=None, residual=None, relu=False, conv=None, key="_mfma_wperm"):
+    """Inference: 3x3 / stride 1 / pad 1 convolution with the (folded) weight `w`, + bias + residual + ReLU in
+    the kernel's epilogue.  The permuted weights are cached on `owner` (under `key`) for as long as `w` is the
+    same, unmodified tensor.  `conv`, when given, is the module whose geometry must be the kernel's.
+    Returns None when the shape is not the kernel's."""
+    ok = usable(conv, x) if conv is not None else (tuple(w.shape[2:]) == (3, 3) and usable_shape(x, w.shape[0]))
+    if not ok or w.shape[1] != x.shape[1] or (residual is not None and not residual.is_contiguous()):
+        return None
+    cache = owner.__dict__.get(key)
+    if cache is None or cache[0] is not w or cache[1] != w._version:
+        cache = (w, w._version, _prepare(w.contiguous(), w.shape[1], w.shape[0], False))
+        owner.__dict__[key] = cache
+    return _launch(x.contiguous(), cache[2], bias, residual, w.shape[0], relu)
+
+
+class _Conv3x3Fn(torch.autograd.Function):
+    """Training: forward and input gradient on the matrix cores (the input gradient is the same kernel
+    over grad_out with the transposed, flipped weights); weight gradient from the library."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        ctx.save_for_backward(x, weight)
+        cout, cin = weight.shape[0], weight.shape[1]
+        return _launch(x, _prepare(weight, cin, cout, False), None, None, cout, False)
+
+    @staticmethod
+    def backward(ctx, go):
+        x, weight = ctx.saved_tensors
+        go = go.contiguous()
+        cout, cin = weight.shape[0], weight.shape[1]
+        gx = gw = None
+        if ctx.needs_input_grad[0]:
+            B, _, H, W = x.shape
+            if cout >= MIN_CIN and _C.lib().cp_conv3x3_mfma_supported(cout, cin, H, W):
+                gx = _launch(go, _prepare(weight, cout, cin, True), None, None, cin, False)
+            else:
+                gx = torch.nn.grad.conv2d_input(x.shape, weight, go, padding=1)
+        if ctx.needs_input_grad[1]:
+            gw = torch.nn.grad.conv2d_weight(x, weight.shape, go, padding=1)
+        return gx, gw
+
+
+def conv_raw(conv, x):
+    """conv(x) WITHOUT its bias, differentiable: the MFMA kernel for its shapes, the library otherwise."""
+    if usable(conv, x):
+        return _Conv3x3Fn.apply(x.contiguous(), conv.weight)
+    return F.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation, conv.groups)

@@ -14,7 +14,8 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ... import _C
-from .pose_dla_dcn import _conv_folded, _fold_conv_bn, _use_folded, bn_act
+from .conv3x3 import conv3x3_infer
+from .pose_dla_dcn import _conv_folded, _fold_conv_bn, _use_folded, bn_act, conv_train
 
 # Inference (`prepare_inference()`): every BatchNorm is folded into its convolution (weights scaled,
 # shift as a bias) and each conv is followed by ONE fused in-place pass -- + bias (+ residual) (+ ReLU),
@@ -42,7 +43,7 @@ class convolution(nn.Module):
         if _use_folded(self):
             return _conv_folded(x, self.conv, self._folded, relu=True)
         if isinstance(self.bn, nn.BatchNorm2d):
-            return bn_act(self.bn, self.conv(x), relu=True)     # fused BN+ReLU in training
+            return bn_act(self.bn, conv_train(self.conv, x), relu=True)     # fused BN+ReLU in training
         return self.relu(self.bn(self.conv(x)))
 
 
@@ -71,8 +72,8 @@ class residual(nn.Module):
             skip = x if fs is None else _conv_folded(x, self.skip[0], fs, relu=False)
             y = _conv_folded(x, self.conv1, f1, relu=True)
             return _conv_folded(y, self.conv2, f2, relu=True, residual=skip)
-        y = bn_act(self.bn1, self.conv1(x), relu=True)
-        return bn_act(self.bn2, self.conv2(y), relu=True, residual=self.skip(x))
+        y = bn_act(self.bn1, conv_train(self.conv1, x), relu=True)
+        return bn_act(self.bn2, conv_train(self.conv2, y), relu=True, residual=self.skip(x))
 
 
 def _stack(first, rest_dim, count, tail=None):
@@ -188,7 +189,9 @@ class exkp(nn.Module):
 
     def _heads_fast(self, s, cnv):
         w, b, tails = self._heads_cat[s]
-        y = F.conv2d(cnv, w, None, padding=1)
+        y = conv3x3_infer(cnv, self, w, key="_heads_wperm%d" % s)
+        if y is None:
+            y = F.conv2d(cnv, w, None, padding=1)
         B, ctot, H, W = y.shape
         hw = H * W
         out, c0 = {}, 0

@@ -19,6 +19,7 @@ from torch import nn
 
 from ... import _C
 from .DCNv2.dcn_v2 import DCN, conv_bias
+from .conv3x3 import conv3x3_infer, conv_raw
 
 BN_MOMENTUM = 0.1
 
@@ -108,6 +109,8 @@ def conv_train(conv, x):
             and _C.lib().cp_conv_direct_supported(conv.in_channels, conv.out_channels, kh, conv.stride[0],
                                                   conv.padding[0])):
         return _DirectConvFn.apply(x.contiguous(), conv.weight, conv.stride[0], conv.padding[0])
+    if conv.bias is None:
+        return conv_raw(conv, x)                    # split-bf16 MFMA kernel for 3x3 / stride 1, else the library
     return conv(x)
 
 
@@ -115,6 +118,10 @@ def _conv_folded(x, conv, wb, relu=False, residual=None):
     """conv with folded-BN weights, then ONE fused in-place pass: + bias (+ residual) (+ ReLU)."""
     if residual is None:
         y = _conv_direct(x, conv, wb, relu)
+        if y is not None:
+            return y
+    if x.is_cuda:
+        y = conv3x3_infer(x, conv, wb[0], wb[1], residual, relu, conv=conv)
         if y is not None:
             return y
     if not x.is_cuda:
@@ -165,7 +172,7 @@ def conv_bias_relu(conv, x):
     """conv (with bias) followed by ReLU: fused epilogue on a HIP device in training."""
     if (x.is_cuda and conv.bias is not None and x.dtype == torch.float32 and torch.is_grad_enabled()
             and conv.groups == 1):
-        y = F.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation)
+        y = conv_raw(conv, x)
         if y.is_contiguous() and (y.shape[2] * y.shape[3]) % 4 == 0 and y.shape[0] * y.shape[1] <= 65535:
             return _BiasRelu.apply(y, conv.bias)
         return F.relu(y + conv.bias.view(1, -1, 1, 1))
@@ -246,8 +253,8 @@ class BasicBlock(nn.Module):
         if _use_folded(self):
             y = _conv_folded(x, self.conv1, self._folded[0], relu=True)
             return _conv_folded(y, self.conv2, self._folded[1], relu=True, residual=skip)
-        y = bn_act(self.bn1, self.conv1(x), relu=True)
-        return bn_act(self.bn2, self.conv2(y), relu=True, residual=skip)
+        y = bn_act(self.bn1, conv_train(self.conv1, x), relu=True)
+        return bn_act(self.bn2, conv_train(self.conv2, y), relu=True, residual=skip)
 
 
 class Root(nn.Module):
@@ -600,7 +607,9 @@ class DLASeg(nn.Module):
         raw result (cp_conv1x1_act_forward) -- the 4x256-channel tensor is read once instead of
         going through a bias/ReLU pass and a GEMM with a handful of output rows."""
         w, b, tails = self._heads_cat
-        y = F.conv2d(feat, w, None, padding=1)
+        y = conv3x3_infer(feat, self, w, key="_heads_wperm")
+        if y is None:
+            y = F.conv2d(feat, w, None, padding=1)
         B, ctot, H, W = y.shape
         hw = H * W
         out, c0 = {}, 0

@@ -166,6 +166,24 @@ int cp_conv_direct_forward(const float* x, const float* w, const float* bias, fl
                            int32_t H, int32_t W, int32_t Cout, int32_t k, int32_t stride, int32_t pad,
                            int32_t relu, void* stream);
 
+/* 3x3 / stride 1 / pad 1 convolution of float32 NCHW maps on the bf16 matrix cores (split-bf16 x3: float32 in and
+ * out, ~2^-16 relative error per product): the dense convolutions of BasicBlock (src/lib/models/networks/
+ * pose_dla_dcn.py:38-66), of the heads' `fc` (:445-462), of DCN.conv_offset_mask (DCNv2/dcn_v2.py:137-145) and of
+ * large_hourglass.py's convolution / residual (:24-37, :55-81) -- what the reference hands to cuDNN.
+ *   out[b][co][y][x] = act(bias[co] + residual[b][co][y][x] + sum w[co][ci][ky][kx] * x[b][ci][y - 1 + ky][x - 1 + kx])
+ * The weights are split and permuted once by cp_conv3x3_mfma_prepare into `wperm` (cp_conv3x3_mfma_weight_bytes);
+ * with transposed = 1 the prologue reads a [Cin][Cout][3][3] tensor as its transposed, flipped self, so that the
+ * same kernel computes the INPUT GRADIENT of the convolution whose weight that tensor is (x := grad_out).
+ * The contraction runs in steps of 32 input channels (a ragged last step is zero-filled); tensors must stay within
+ * 32-bit byte offsets per image: cp_conv3x3_mfma_supported tells, anything else returns CP_EUNSUPPORTED.
+ * bias, residual may be NULL. */
+int cp_conv3x3_mfma_supported(int32_t Cin, int32_t Cout, int32_t H, int32_t W);
+size_t cp_conv3x3_mfma_weight_bytes(int32_t Cin, int32_t Cout);
+int cp_conv3x3_mfma_prepare(const float* weight, int32_t Cin, int32_t Cout, int32_t transposed, void* wperm,
+                            void* stream);
+int cp_conv3x3_mfma_forward(const float* x, const void* wperm, const float* bias, const float* residual, float* out,
+                            int32_t B, int32_t Cin, int32_t H, int32_t W, int32_t Cout, int32_t relu, void* stream);
+
 /* Output stage of a detection head at inference (the `fc` Sequential of DLASeg,
  * src/lib/models/networks/pose_dla_dcn.py:445-462: Conv2d 3x3 + bias -> ReLU -> Conv2d 1x1 + bias),
  * everything after the 3x3 convolution's matrix product, one pass:

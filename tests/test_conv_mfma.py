@@ -1,0 +1,126 @@
+"""GPU parity of the split-bf16 MFMA 3x3 convolution (csrc/conv_mfma.hip) through the C ABI.
+
+float64 torch convolution is the checker (a floating-point kernel: plain torch reference, per the task's rule
+for such kernels).  Tolerance: every product is formed from bf16 halves hi*hi + hi*lo + lo*hi, i.e. with a
+relative error <= ~2^-16 before the float32 accumulation; measured 4e-6 of the output's max-norm on the layer
+shapes of DLA-34, asserted at 2e-5 -- fifty times inside the path's 1e-3 bar."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from centerpoly_amd import _C, synth
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+TOL = 2e-5
+
+
+def P(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _t(tag, shape, scale=1.0):
+    return torch.from_numpy(synth.normal("convmfma/" + tag, shape) * np.float32(scale)).to(DEV)
+
+
+def _conv(x, w, bias=None, residual=None, relu=False, transposed=False):
+    L = _C.lib()
+    B, cin, H, W = x.shape
+    cout = w.shape[1] if transposed else w.shape[0]
+    assert L.cp_conv3x3_mfma_supported(cin, cout, H, W)
+    wp = torch.empty(L.cp_conv3x3_mfma_weight_bytes(cin, cout), dtype=torch.uint8, device=DEV)
+    _C.check(L.cp_conv3x3_mfma_prepare(P(w), cin, cout, 1 if transposed else 0, P(wp), _C.stream()), "prepare")
+    out = torch.full((B, cout, H, W), float("nan"), device=DEV)
+    _C.check(L.cp_conv3x3_mfma_forward(P(x), P(wp), P(bias), P(residual), P(out), B, cin, H, W, cout,
+                                       1 if relu else 0, _C.stream()), "forward")
+    return out
+
+
+def _rel(a, ref):
+    return (a.double() - ref).abs().max().item() / max(ref.abs().max().item(), 1e-30)
+
+
+# (B, Cin, Cout, H, W): the layer families of DLA-34 / Hourglass plus ragged edges -- map sizes that are not a
+# multiple of the 8 x 32 (16 x 32) tile, output channels that do not fill a 16-row fragment (27, 80), input
+# channels that do not fill the 32-channel step (27, 48), a single tile, one row, one column
+SHAPES = [(2, 64, 64, 32, 64), (1, 64, 256, 40, 72), (2, 64, 27, 24, 80), (1, 128, 128, 17, 33),
+          (3, 32, 80, 9, 31), (1, 256, 96, 8, 32), (2, 27, 64, 12, 40), (1, 48, 16, 5, 7), (1, 32, 32, 1, 50),
+          (1, 32, 48, 37, 1), (1, 512, 64, 6, 10)]
+
+
+@pytest.mark.parametrize("shape", SHAPES, ids=["x".join(map(str, s)) for s in SHAPES])
+def test_forward_matches_float64_convolution(shape):
+    B, ci, co, H, W = shape
+    x, w = _t("x%s" % (shape,), (B, ci, H, W)), _t("w%s" % (shape,), (co, ci, 3, 3), 0.05)
+    ref = F.conv2d(x.double(), w.double(), padding=1)
+    out = _conv(x, w)
+    assert torch.isfinite(out).all()                      # every output element was written
+    assert _rel(out, ref) <= TOL
+
+
+@pytest.mark.parametrize("shape", [SHAPES[0], SHAPES[2], SHAPES[4]], ids=["64", "27", "80"])
+def test_epilogue_bias_residual_relu(shape):
+    B, ci, co, H, W = shape
+    x, w = _t("ex", (B, ci, H, W)), _t("ew", (co, ci, 3, 3), 0.05)
+    bias, res = _t("eb", (co,)), _t("er", (B, co, H, W))
+    lin = F.conv2d(x.double(), w.double(), bias.double(), padding=1)
+    assert _rel(_conv(x, w, bias=bias), lin) <= TOL
+    assert _rel(_conv(x, w, bias=bias, relu=True), F.relu(lin)) <= TOL
+    full = F.relu(lin + res.double())
+    out = _conv(x, w, bias=bias, residual=res, relu=True)
+    assert _rel(out, full) <= TOL
+    assert (out >= 0).all()
+
+
+@pytest.mark.parametrize("shape", [SHAPES[0], SHAPES[1], SHAPES[2], SHAPES[4], SHAPES[6]],
+                         ids=["64->64", "64->256", "64->27", "32->80", "27->64"])
+def test_input_gradient_through_transposed_weights(shape):
+    """grad_in = conv(grad_out, W transposed and flipped): the prologue's `transposed` mode, ragged K = Cout."""
+    B, ci, co, H, W = shape
+    w, go = _t("gw", (co, ci, 3, 3), 0.05), _t("ggo", (B, co, H, W))
+    ref = torch.nn.grad.conv2d_input((B, ci, H, W), w.double(), go.double(), padding=1)
+    assert _rel(_conv(go, w, transposed=True), ref) <= TOL
+
+
+def test_linearity_and_determinism():
+    x1, x2, w = _t("l1", (2, 64, 24, 64)), _t("l2", (2, 64, 24, 64)), _t("lw", (64, 64, 3, 3), 0.05)
+    a, b, c = _conv(x1, w), _conv(x2, w), _conv(x1 + x2, w)
+    assert (a + b - c).abs().max().item() <= TOL * c.abs().max().item()
+    assert torch.equal(_conv(x1, w), a)                   # no atomics, fixed order: bit-identical reruns
+    assert torch.equal(_conv(2.0 * x1, w), 2.0 * a)       # power-of-two scaling commutes with the bf16 split
+
+
+def test_zero_padding_and_impulse():
+    """An impulse input returns the flipped kernel around it; borders see zeros, not neighbours' rows."""
+    w = _t("iw", (32, 32, 3, 3))
+    x = torch.zeros((1, 32, 8, 32), device=DEV)
+    x[0, 5, 0, 0] = 1.0
+    x[0, 7, 7, 31] = 1.0
+    out = _conv(x, w)
+    ref = F.conv2d(x.double(), w.double(), padding=1)
+    assert _rel(out, ref) <= TOL
+    assert (out[0, :, 3:5, 8:24] == 0).all()
+
+
+def test_autograd_wrapper_against_library():
+    from centerpoly_amd.models.networks import conv3x3
+    conv = torch.nn.Conv2d(64, 96, 3, padding=1, bias=False).to(DEV)
+    x = _t("ax", (4, 64, 48, 64)).requires_grad_(True)
+    assert conv3x3.usable(conv, x)
+    y = conv3x3.conv_raw(conv, x)
+    go = _t("ago", tuple(y.shape))
+    gx, gw = torch.autograd.grad(y, (x, conv.weight), go)
+    xd = x.detach().double().requires_grad_(True)
+    wd = conv.weight.detach().double().requires_grad_(True)
+    yd = F.conv2d(xd, wd, padding=1)
+    gxd, gwd = torch.autograd.grad(yd, (xd, wd), go.double())
+    assert _rel(y, yd.detach()) <= TOL and _rel(gx, gxd) <= TOL and _rel(gw, gwd) <= 1e-4
+
+
+def test_unsupported_and_bad_arguments():
+    L = _C.lib()
+    assert not L.cp_conv3x3_mfma_supported(64, 64, 40000, 40000)          # beyond 32-bit offsets
+    assert L.cp_conv3x3_mfma_forward(None, None, None, None, None, 1, 64, 8, 8, 64, 0, _C.stream()) != 0
