@@ -273,3 +273,256 @@ int cp_conv3x3_mfma_forward(const float* x, const void* wperm, const float* bias
 }
 
 }  // extern "C"
+
+// =====================================================================================================================
+// Weight gradient of the same convolution, same arithmetic (split-bf16 x3 on the bf16 matrix cores):
+//   gw[co][ci][dy][dx] += sum_{b, y, x} go[b][co][y][x] * in[b][ci][y + dy - 1][x + dx - 1]
+// GEMM view: D[co][ci] (one per tap) += A[co][px] * B[px][ci], contraction over PIXELS, k-step = 32 pixels of one row.
+//   * workgroup = (a run of 4 x 32 pixel tiles, 64 input channels, 32 MTW output channels), 8 waves; wave w owns
+//     input-channel fragment w & 3 and MTW output-channel fragments, all 9 taps: 9 * MTW accumulator tiles.
+//   * per pixel tile both operands are loaded as float4 (prefetched a tile ahead into registers), split once and stored
+//     as bf16 hi / lo planes: go as [co][4 rows x 32 px] (pitch 136), in as [ci][6 rows][48 px] (pitch 296, the tile's
+//     column 0 at element 8) -- both pitches are an odd number of 16-byte units, so the 16 lanes of a fragment read
+//     hit 16 different bank groups.
+//   * an A fragment (8 consecutive pixels of a go row) is one ds_read_b128 per half.  A B fragment of the centre column
+//     tap is one ds_read_b128 too; the dx = -1 / +1 taps are the same 8 pixels shifted by one bf16: built in registers
+//     from the centre fragment and one neighbouring dword each side with five v_alignbit per half (VALU work that
+//     runs beside the matrix cores), instead of unaligned LDS reads or three shifted copies.
+//   * flush: accumulators -> LDS [32 co][64 ci x 9] -> one coalesced float atomicAdd per element (each output row
+//     of a workgroup is 576 contiguous floats of gw).
+// =====================================================================================================================
+namespace {
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+struct WgArgs {
+  const float* x;
+  const float* go;
+  float* gw;
+  int Cin, Cout, H, W, tiles_x, tiles_y, ntiles, tiles_per_wg, n_ci;
+};
+
+constexpr int WG_GP = 4 * 32 + 8;          // go pitch per output channel (bf16 elements)
+constexpr int WG_XR = 48;                  // in: row pitch
+constexpr int WG_XP = 6 * WG_XR + 8;       // in: channel pitch
+constexpr int WG_CI = 64;
+
+__device__ __forceinline__ void split4(const f32x4 v, u32x2& hi, u32x2& lo) {
+  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+  bf16x2 h0, h1, l0, l1;
+  h0[0] = (__bf16)v.x;
+  h0[1] = (__bf16)v.y;
+  h1[0] = (__bf16)v.z;
+  h1[1] = (__bf16)v.w;
+  l0[0] = (__bf16)(v.x - (float)h0[0]);
+  l0[1] = (__bf16)(v.y - (float)h0[1]);
+  l1[0] = (__bf16)(v.z - (float)h1[0]);
+  l1[1] = (__bf16)(v.w - (float)h1[1]);
+  hi = u32x2{__builtin_bit_cast(unsigned, h0), __builtin_bit_cast(unsigned, h1)};
+  lo = u32x2{__builtin_bit_cast(unsigned, l0), __builtin_bit_cast(unsigned, l1)};
+}
+
+template <int MTW>
+__global__ __launch_bounds__(512, 2) void conv3x3_wgrad_kernel(WgArgs a) {
+  constexpr int CO = 32 * MTW;
+  constexpr int G_PLANE = CO * WG_GP, X_PLANE = WG_CI * WG_XP;                 // elements per half
+  constexpr int G_ITERS = CO * 32 / 512, X_UNITS = WG_CI * 60, X_ITERS = (X_UNITS + 511) / 512;
+  constexpr int STAGE_BYTES = (2 * G_PLANE + 2 * X_PLANE) * 2;
+  constexpr int OP = WG_CI * 9 + 1, OUT_BYTES = 32 * OP * 4;
+  constexpr int SMEM = STAGE_BYTES > OUT_BYTES ? STAGE_BYTES : OUT_BYTES;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];
+  unsigned short* Gs = reinterpret_cast<unsigned short*>(smem);                // [2][G_PLANE]
+  unsigned short* Xs = Gs + 2 * G_PLANE;                                       // [2][X_PLANE]
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, g = lane >> 4, c = lane & 15;
+  const int nt = wid & 3, mtb = (wid >> 2) * MTW;
+  const int ci0 = (blockIdx.y % a.n_ci) * WG_CI, co0 = (blockIdx.y / a.n_ci) * CO;
+  const int HW = a.H * a.W;
+  const int k_begin = blockIdx.x * a.tiles_per_wg;
+  const int k_end = min(a.ntiles, k_begin + a.tiles_per_wg);
+
+  f32x4 acc[9][MTW];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int m = 0; m < MTW; ++m) acc[t][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // staging units of this thread (tile-independent parts)
+  int g_lds[G_ITERS], g_rc[G_ITERS];          // LDS element; packed (co, row, col)
+#pragma unroll
+  for (int i = 0; i < G_ITERS; ++i) {
+    const int u = tid + i * 512, q4 = u & 7, r = (u >> 3) & 3, co = u >> 5;
+    g_lds[i] = co * WG_GP + r * 32 + 4 * q4;
+    g_rc[i] = (co << 16) | (r << 8) | (4 * q4);
+  }
+  int x_lds[X_ITERS], x_rc[X_ITERS];
+#pragma unroll
+  for (int i = 0; i < X_ITERS; ++i) {
+    const int u = tid + i * 512;
+    const int q = u % 10, rr = (u / 10) % 6, ci = u / 60;
+    x_lds[i] = u < X_UNITS ? ci * WG_XP + rr * WG_XR + 4 + 4 * q : -1;
+    x_rc[i] = (ci << 16) | (rr << 8) | (4 * q);
+  }
+
+  f32x4 gv[G_ITERS], xv[X_ITERS];
+  auto load_tile = [&](int k) __attribute__((always_inline)) {
+    const int tx = k % a.tiles_x, ty = (k / a.tiles_x) % a.tiles_y, b = k / (a.tiles_x * a.tiles_y);
+    const int x0 = tx * 32, y0 = ty * 4;
+    const __amdgpu_buffer_rsrc_t rs_g = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.go + (long long)b * a.Cout * HW), 0, (int)((unsigned)a.Cout * (unsigned)HW * 4u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.x + (long long)b * a.Cin * HW), 0, (int)((unsigned)a.Cin * (unsigned)HW * 4u), 0x00020000);
+#pragma unroll
+    for (int i = 0; i < G_ITERS; ++i) {
+      const int co = co0 + (g_rc[i] >> 16), y = y0 + ((g_rc[i] >> 8) & 255), x = x0 + (g_rc[i] & 255);
+      const bool ok = co < a.Cout && y < a.H && x < a.W;
+      const unsigned off = ok ? ((unsigned)co * (unsigned)HW + (unsigned)(y * a.W + x)) * 4u : OOB;
+      gv[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_g, off, 0, 0));
+    }
+#pragma unroll
+    for (int i = 0; i < X_ITERS; ++i) {
+      const int ci = ci0 + (x_rc[i] >> 16), y = y0 - 1 + ((x_rc[i] >> 8) & 255), x = x0 - 4 + (x_rc[i] & 255);
+      const bool ok = x_lds[i] >= 0 && ci < a.Cin && y >= 0 && y < a.H && x >= 0 && x < a.W;
+      const unsigned off = ok ? ((unsigned)ci * (unsigned)HW + (unsigned)(y * a.W + x)) * 4u : OOB;
+      xv[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, off, 0, 0));
+    }
+  };
+
+  if (k_begin < k_end) load_tile(k_begin);
+
+  // fragment bases of this lane
+  const int a_base = c * WG_GP + 8 * g;                              // + (mtb + m) * 16 * GP + r * 32
+  const int b_base = (nt * 16 + c) * WG_XP + 8 + 8 * g;              // + (r + dy) * XR
+
+  for (int k = k_begin; k < k_end; ++k) {
+    __syncthreads();                                                 // the previous tile's fragments have been read
+#pragma unroll
+    for (int i = 0; i < G_ITERS; ++i) {
+      u32x2 hi, lo;
+      split4(gv[i], hi, lo);
+      *reinterpret_cast<u32x2*>(&Gs[g_lds[i]]) = hi;
+      *reinterpret_cast<u32x2*>(&Gs[G_PLANE + g_lds[i]]) = lo;
+    }
+#pragma unroll
+    for (int i = 0; i < X_ITERS; ++i) {
+      if (x_lds[i] >= 0) {
+        u32x2 hi, lo;
+        split4(xv[i], hi, lo);
+        *reinterpret_cast<u32x2*>(&Xs[x_lds[i]]) = hi;
+        *reinterpret_cast<u32x2*>(&Xs[X_PLANE + x_lds[i]]) = lo;
+      }
+    }
+    __syncthreads();
+    if (k + 1 < k_end) load_tile(k + 1);                             // in flight during the matrix phase
+
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      bf16x8 ah[MTW], al[MTW];
+#pragma unroll
+      for (int m = 0; m < MTW; ++m) {
+        const int e = a_base + (mtb + m) * 16 * WG_GP + r * 32;
+        ah[m] = *reinterpret_cast<const bf16x8*>(&Gs[e]);
+        al[m] = *reinterpret_cast<const bf16x8*>(&Gs[G_PLANE + e]);
+      }
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy) {
+        const int e = b_base + (r + dy) * WG_XR;
+        u32x4 bh[3], bl[3];                                          // dx = 0 (x - 1), 1 (x), 2 (x + 1)
+#pragma unroll
+        for (int hl = 0; hl < 2; ++hl) {
+          const unsigned short* pl = Xs + hl * X_PLANE + e;
+          const u32x4 q = *reinterpret_cast<const u32x4*>(pl);
+          const unsigned pL = *reinterpret_cast<const unsigned*>(pl - 2);
+          const unsigned pR = *reinterpret_cast<const unsigned*>(pl + 8);
+          const unsigned s01 = __builtin_amdgcn_alignbit(q[1], q[0], 16), s12 = __builtin_amdgcn_alignbit(q[2], q[1], 16),
+                         s23 = __builtin_amdgcn_alignbit(q[3], q[2], 16);
+          u32x4* dst = hl ? bl : bh;
+          dst[0] = u32x4{__builtin_amdgcn_alignbit(q[0], pL, 16), s01, s12, s23};
+          dst[1] = q;
+          dst[2] = u32x4{s01, s12, s23, __builtin_amdgcn_alignbit(pR, q[3], 16)};
+        }
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+          const bf16x8 fh = __builtin_bit_cast(bf16x8, bh[dx]), fl = __builtin_bit_cast(bf16x8, bl[dx]);
+#pragma unroll
+          for (int m = 0; m < MTW; ++m) {
+            f32x4 v = acc[dy * 3 + dx][m];
+            v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[m], fh, v, 0, 0, 0);
+            v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[m], fl, v, 0, 0, 0);
+            v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[m], fh, v, 0, 0, 0);
+            acc[dy * 3 + dx][m] = v;
+          }
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+
+  // ---- flush: 32 output channels per pass through LDS, then coalesced atomics ----
+  float* O = reinterpret_cast<float*>(smem);
+  const int ciw = min(WG_CI, a.Cin - ci0) * 9;
+#pragma unroll
+  for (int pass = 0; pass < CO / 32; ++pass) {
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < MTW; ++m) {
+      const int row0 = (mtb + m) * 16 + 4 * g;                       // rows row0 .. row0 + 3 lie in one pass
+      if (row0 / 32 == pass) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) O[(row0 % 32 + r) * OP + (nt * 16 + c) * 9 + t] = acc[t][m][r];
+      }
+    }
+    __syncthreads();
+    for (int idx = tid; idx < 32 * ciw; idx += 512) {
+      const int row = idx / ciw, col = idx - row * ciw;
+      const int co = co0 + pass * 32 + row;
+      if (co < a.Cout) atomicAdd(&a.gw[((long long)co * a.Cin + ci0) * 9 + col], O[row * OP + col]);
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int cp_conv3x3_mfma_wgrad_supported(int32_t Cin, int32_t Cout, int32_t H, int32_t W) {
+  return Cin >= 1 && Cout >= 1 && H >= 1 && W >= 4 && W % 4 == 0 && (long long)Cin * H * W * 4 < 0x7FFFFFF0ll &&
+         (long long)Cout * H * W * 4 < 0x7FFFFFF0ll;
+}
+
+// gw [Cout][Cin][3][3] += the weight gradient (the caller zeroes or carries an accumulation).
+int cp_conv3x3_mfma_wgrad(const float* x, const float* go, float* gw, int32_t B, int32_t Cin, int32_t H, int32_t W,
+                          int32_t Cout, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  CP_CHECK_ARG(x && go && gw && B >= 1);
+  if (!cp_conv3x3_mfma_wgrad_supported(Cin, Cout, H, W)) return CP_EUNSUPPORTED;
+  WgArgs a;
+  a.x = x;
+  a.go = go;
+  a.gw = gw;
+  a.Cin = Cin;
+  a.Cout = Cout;
+  a.H = H;
+  a.W = W;
+  a.tiles_x = (W + 31) / 32;
+  a.tiles_y = (H + 3) / 4;
+  a.ntiles = a.tiles_x * a.tiles_y * B;
+  a.n_ci = (Cin + WG_CI - 1) / WG_CI;
+  const int MTW = Cout <= 32 ? 1 : 2;
+  const int n_co = (Cout + 32 * MTW - 1) / (32 * MTW);
+  const int pairs = a.n_ci * n_co;
+  int nsplit = (512 + pairs - 1) / pairs;                            // ~2 workgroups per CU
+  if (nsplit > a.ntiles) nsplit = a.ntiles;
+  a.tiles_per_wg = (a.ntiles + nsplit - 1) / nsplit;
+  nsplit = (a.ntiles + a.tiles_per_wg - 1) / a.tiles_per_wg;
+  if (MTW == 2)
+    hipLaunchKernelGGL((conv3x3_wgrad_kernel<2>), dim3(nsplit, pairs), dim3(512), 0, st, a);
+  else
+    hipLaunchKernelGGL((conv3x3_wgrad_kernel<1>), dim3(nsplit, pairs), dim3(512), 0, st, a);
+  return cp_launch_status();
+}
+
+}  // extern "C"

@@ -3,7 +3,7 @@ cp_conv3x3_mfma_*): the dense 3x3 / stride 1 / pad 1 convolutions of the referen
 (src/lib/models/networks/pose_dla_dcn.py BasicBlock :38-66, heads :445-462, DCNv2/dcn_v2.py:137-145
 conv_offset_mask; large_hourglass.py convolution :24-37, residual :55-81), which the reference hands
 to cuDNN.  float32 in and out; forward and input gradient run on the bf16 matrix cores as three
-products of split halves, the weight gradient is the library's.
+products of split halves, and so does the weight gradient (cp_conv3x3_mfma_wgrad).
 
 `conv_raw(conv, x)` is what every training call site uses for "conv without its bias";
 `conv3x3_infer(x, conv, w, bias, residual, relu)` is the inference call with the fused epilogue.
@@ -17,6 +17,7 @@ import torch.nn.functional as F
 from ... import _C
 
 _ENABLED = os.environ.get("CP_CONV_MFMA", "1") != "0"
+_WGRAD = os.environ.get("CP_CONV_MFMA_WGRAD", "1") != "0"
 MIN_CIN = 24                 # the contraction steps over 32 input channels: fewer would mostly multiply zeros
 MIN_WORKGROUPS = 96          # below this the launch cannot fill the 256 CUs and the library is faster
 
@@ -77,7 +78,7 @@ def conv3x3_infer(x, owner, w, bias=None, residual=None, relu=False, conv=None, 
 
 class _Conv3x3Fn(torch.autograd.Function):
     """Training: forward and input gradient on the matrix cores (the input gradient is the same kernel
-    over grad_out with the transposed, flipped weights); weight gradient from the library."""
+    over grad_out with the transposed, flipped weights); weight gradient by cp_conv3x3_mfma_wgrad."""
 
     @staticmethod
     def forward(ctx, x, weight):
@@ -98,7 +99,13 @@ class _Conv3x3Fn(torch.autograd.Function):
             else:
                 gx = torch.nn.grad.conv2d_input(x.shape, weight, go, padding=1)
         if ctx.needs_input_grad[1]:
-            gw = torch.nn.grad.conv2d_weight(x, weight.shape, go, padding=1)
+            B, _, H, W = x.shape
+            if _WGRAD and _C.lib().cp_conv3x3_mfma_wgrad_supported(cin, cout, H, W):
+                gw = torch.zeros_like(weight)
+                _C.check(_C.lib().cp_conv3x3_mfma_wgrad(_C.ptr(x), _C.ptr(go), _C.ptr(gw), B, cin, H, W, cout,
+                                                        _C.stream()), "cp_conv3x3_mfma_wgrad")
+            else:
+                gw = torch.nn.grad.conv2d_weight(x, weight.shape, go, padding=1)
         return gx, gw
 
 

@@ -184,6 +184,14 @@ int cp_conv3x3_mfma_prepare(const float* weight, int32_t Cin, int32_t Cout, int3
 int cp_conv3x3_mfma_forward(const float* x, const void* wperm, const float* bias, const float* residual, float* out,
                             int32_t B, int32_t Cin, int32_t H, int32_t W, int32_t Cout, int32_t relu, void* stream);
 
+/* Weight gradient of the same convolution, same arithmetic (what the reference gets from cuDNN's backward-filter):
+ *   gw[co][ci][ky][kx] += sum_{b,y,x} go[b][co][y][x] * x[b][ci][y - 1 + ky][x - 1 + kx]
+ * gw [Cout][Cin][3][3] is ACCUMULATED into (float atomics: zero it first; the summation order varies from run to
+ * run in the last bits).  Needs W % 4 == 0; cp_conv3x3_mfma_wgrad_supported tells, else CP_EUNSUPPORTED. */
+int cp_conv3x3_mfma_wgrad_supported(int32_t Cin, int32_t Cout, int32_t H, int32_t W);
+int cp_conv3x3_mfma_wgrad(const float* x, const float* go, float* gw, int32_t B, int32_t Cin, int32_t H, int32_t W,
+                          int32_t Cout, void* stream);
+
 /* Output stage of a detection head at inference (the `fc` Sequential of DLASeg,
  * src/lib/models/networks/pose_dla_dcn.py:445-462: Conv2d 3x3 + bias -> ReLU -> Conv2d 1x1 + bias),
  * everything after the 3x3 convolution's matrix product, one pass:

@@ -124,3 +124,48 @@ def test_unsupported_and_bad_arguments():
     L = _C.lib()
     assert not L.cp_conv3x3_mfma_supported(64, 64, 40000, 40000)          # beyond 32-bit offsets
     assert L.cp_conv3x3_mfma_forward(None, None, None, None, None, 1, 64, 8, 8, 64, 0, _C.stream()) != 0
+
+
+def _wgrad(x, go, cout):
+    L = _C.lib()
+    B, cin, H, W = x.shape
+    assert L.cp_conv3x3_mfma_wgrad_supported(cin, cout, H, W)
+    gw = torch.zeros((cout, cin, 3, 3), device=DEV)
+    _C.check(L.cp_conv3x3_mfma_wgrad(P(x), P(go), P(gw), B, cin, H, W, cout, _C.stream()), "wgrad")
+    return gw
+
+
+# ragged everything: rows not a multiple of 4, widths not a multiple of 32, 27 / 80 / 200 channels, several
+# pixel tiles per workgroup and fewer tiles than workgroups
+WG_SHAPES = [(2, 64, 64, 32, 64), (1, 64, 256, 40, 72), (2, 64, 27, 24, 80), (1, 128, 128, 17, 36), (3, 32, 80, 9, 28),
+             (2, 27, 64, 12, 40), (1, 200, 48, 5, 8), (1, 32, 32, 1, 52), (1, 32, 48, 37, 4), (1, 512, 64, 6, 12),
+             (4, 64, 64, 128, 256)]
+
+
+@pytest.mark.parametrize("shape", WG_SHAPES, ids=["x".join(map(str, s)) for s in WG_SHAPES])
+def test_weight_gradient_matches_float64(shape):
+    B, ci, co, H, W = shape
+    x, go = _t("wx%s" % (shape,), (B, ci, H, W)), _t("wgo%s" % (shape,), (B, co, H, W))
+    ref = torch.nn.grad.conv2d_weight(x.double(), (co, ci, 3, 3), go.double(), padding=1)
+    gw = _wgrad(x, go, co)
+    assert _rel(gw, ref) <= TOL
+    # accumulation semantics: a second call adds onto the first
+    L = _C.lib()
+    _C.check(L.cp_conv3x3_mfma_wgrad(P(x), P(go), P(gw), B, ci, H, W, co, _C.stream()), "wgrad")
+    assert _rel(gw, 2.0 * ref) <= TOL
+
+
+def test_weight_gradient_adjoint_identity():
+    """<conv(x, w), go> == <w, wgrad(x, go)> with the forward of the same library: an oracle-free check."""
+    x, w, go = _t("jx", (2, 64, 40, 96)), _t("jw", (96, 64, 3, 3), 0.05), _t("jgo", (2, 96, 40, 96))
+    lhs = (_conv(x, w).double() * go.double()).sum().item()
+    rhs = (w.double() * _wgrad(x, go, 96).double()).sum().item()
+    norm = (_conv(x, w).double().abs() * go.double().abs()).sum().item()
+    assert abs(lhs - rhs) <= 1e-5 * norm
+
+
+def test_wgrad_refuses_unaligned_width():
+    L = _C.lib()
+    assert not L.cp_conv3x3_mfma_wgrad_supported(64, 64, 8, 30)
+    x, go, gw = _t("ux", (1, 64, 8, 30)), _t("ugo", (1, 64, 8, 30)), torch.zeros((64, 64, 3, 3), device=DEV)
+    assert L.cp_conv3x3_mfma_wgrad(P(x), P(go), P(gw), 1, 64, 8, 30, 64, _C.stream()) == -2

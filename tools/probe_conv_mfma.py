@@ -51,6 +51,29 @@ def run(B, ci, co, H, W):
         print("      input gradient err %.2e" % ((gx.double() - gref).abs().max().item() / gref.abs().max().item()), flush=True)
 
 
+def run_wgrad(B, ci, co, H, W):
+    x = torch.from_numpy(synth.normal("pc/x", (B, ci, H, W))).to(dev)
+    go = torch.from_numpy(synth.normal("pc/go", (B, co, H, W))).to(dev)
+    gw = torch.zeros((co, ci, 3, 3), device=dev)
+    call = lambda: _C.check(L.cp_conv3x3_mfma_wgrad(P(x), P(go), P(gw), B, ci, H, W, co, _C.stream()), "wgrad")
+    call()
+    ref = torch.nn.grad.conv2d_weight(x.double(), (co, ci, 3, 3), go.double(), padding=1)
+    err = (gw.double() - ref).abs().max().item() / ref.abs().max().item()
+    lib = torch.nn.grad.conv2d_weight(x, (co, ci, 3, 3), go, padding=1)
+    err_lib = (lib.double() - ref).abs().max().item() / ref.abs().max().item()
+    t = timeit(call)
+    tl = timeit(lambda: torch.nn.grad.conv2d_weight(x, (co, ci, 3, 3), go, padding=1))
+    fl = 2.0 * B * ci * co * 9 * H * W
+    print("wgrad B%d %3d->%3d %3dx%3d  mfma %.3f ms (%.0f TF/s)  library %.3f ms (%.0f TF/s)  err %.2e (library %.2e)"
+          % (B, ci, co, H, W, t, fl / t / 1e9, tl, fl / tl / 1e9, err, err_lib), flush=True)
+
+
+if os.environ.get("PROBE_WGRAD", "1") == "1":
+    for shape in [(1, 32, 16, 8, 32), (2, 64, 27, 24, 80), (4, 64, 256, 256, 512), (4, 64, 27, 256, 512),
+                  (4, 64, 64, 128, 256), (4, 128, 128, 64, 128), (4, 256, 256, 32, 64), (4, 512, 512, 16, 32),
+                  (8, 64, 256, 96, 320)]:
+        run_wgrad(*shape)
+
 for shape in [(1, 32, 16, 8, 32), (2, 64, 27, 24, 80), (4, 64, 256, 256, 512), (1, 64, 256, 256, 512), (4, 64, 27, 256, 512),
               (4, 64, 64, 128, 256), (4, 128, 128, 64, 128), (4, 256, 256, 32, 64), (4, 512, 512, 16, 32),
               (1, 64, 1024, 256, 512)]:
