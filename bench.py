@@ -43,6 +43,7 @@ os.makedirs(os.environ["MIOPEN_USER_DB_PATH"], exist_ok=True)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 MFMA_F32_PEAK_TF = 157.3       # dense fp32 matrix peak
+MFMA_BF16_PEAK_TF = 2500.0     # dense bf16 matrix peak (no sparsity)
 HEADS = {"hm": 8, "poly": 32, "pseudo_depth": 1, "reg": 2}
 EXIT_REFUSED = 2
 
@@ -240,9 +241,43 @@ def dcn_roofline(summary, tag="dcn_fwd"):
               "launches": summary[key]["launches"]}
     hbm = dict(common, bound="hbm", achieved=alg_bytes / avg_s / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
                frac=alg_bytes / avg_s / 1e9 / HBM_PEAK_GBS, algorithmic_bytes_per_launch=alg_bytes)
-    mfma = dict(common, bound="mfma", achieved=alg_flops / avg_s / 1e12, peak=MFMA_F32_PEAK_TF, unit="TFLOP/s",
-                frac=alg_flops / avg_s / 1e12 / MFMA_F32_PEAK_TF, algorithmic_flops_per_launch=alg_flops)
+    if tag == "dcn_bwd_data" and os.environ.get("CP_DCN_BWD_F32", "0") != "1":
+        mfma = split_bf16_roofline(common, alg_flops, avg_s)   # this kernel contracts in split-bf16 x3
+    else:
+        mfma = dict(common, bound="mfma", achieved=alg_flops / avg_s / 1e12, peak=MFMA_F32_PEAK_TF, unit="TFLOP/s",
+                    frac=alg_flops / avg_s / 1e12 / MFMA_F32_PEAK_TF, algorithmic_flops_per_launch=alg_flops)
     return hbm, mfma
+
+
+def split_bf16_roofline(common, alg_flops, avg_s):
+    """Matrix-pipe roofline of a kernel that forms every fp32 product from three bf16 MFMA products
+    (hi*hi + hi*lo + lo*hi): the flops it ISSUES are 3x the algorithmic ones and are priced against
+    the dense bf16 peak; the fp32-equivalent rate is reported beside it."""
+    issued = 3.0 * alg_flops
+    return dict(common, bound="mfma", achieved=issued / avg_s / 1e12, peak=MFMA_BF16_PEAK_TF, unit="TFLOP/s",
+                frac=issued / avg_s / 1e12 / MFMA_BF16_PEAK_TF, algorithmic_flops_per_launch=alg_flops,
+                issued_bf16_flops_per_launch=issued, fp32_equivalent_tflops=alg_flops / avg_s / 1e12,
+                arithmetic="split-bf16 x3 on v_mfma_f32_16x16x32_bf16, fp32 accumulate")
+
+
+def conv_roofline(summary, tag="conv3x3_fwd"):
+    """Dominant launch of the split-bf16 3x3 convolution (forward / input gradient, or weight gradient):
+    algorithmic flops 2*9*Cin*Cout*H*W*B, bytes = input + output (+ weights) once."""
+    summary = {k: v for k, v in (summary or {}).items() if k[0] == tag}
+    if not summary:
+        return None, None
+    key = max(summary, key=lambda k: summary[k]["avg_ms"] * summary[k]["launches"])
+    _, cin, cout, h, w, nb = key
+    avg_s = summary[key]["avg_ms"] * 1e-3
+    alg_flops = 2.0 * 9 * cin * cout * h * w * nb
+    alg_bytes = 4.0 * (nb * (cin + cout) * h * w + 9 * cin * cout)
+    name = "conv3x3 weight gradient" if tag == "conv3x3_wgrad" else "conv3x3 forward / input gradient"
+    common = {"traffic": None, "traffic_source": "not measured for this kernel",
+              "kernel": "%s %d->%d @%dx%d" % (name, cin, cout, h, w) + (" x%d images" % nb if nb != 1 else ""),
+              "avg_launch_us": avg_s * 1e6, "launches": summary[key]["launches"]}
+    hbm = dict(common, bound="hbm", achieved=alg_bytes / avg_s / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
+               frac=alg_bytes / avg_s / 1e9 / HBM_PEAK_GBS, algorithmic_bytes_per_launch=alg_bytes)
+    return hbm, split_bf16_roofline(common, alg_flops, avg_s)
 
 
 # --------------------------------------------------------------------- legs ---
@@ -364,6 +399,11 @@ def train_rooflines(summary):
     for tag, name in (("dcn_fwd", "roofline"), ("dcn_bwd_data", "roofline_bwd_data"),
                       ("dcn_bwd_weight", "roofline_bwd_weight")):
         hbm, mfma = dcn_roofline(summary, tag)
+        if mfma is not None:
+            out[name] = mfma
+            out[name + "_hbm"] = hbm
+    for tag, name in (("conv3x3_fwd", "roofline_conv3x3"), ("conv3x3_wgrad", "roofline_conv3x3_wgrad")):
+        hbm, mfma = conv_roofline(summary, tag)
         if mfma is not None:
             out[name] = mfma
             out[name + "_hbm"] = hbm
@@ -550,6 +590,9 @@ def main(argv=None):
                         "K=128, forward + sigmoid + NMS/top-k/decode" % (args.height, args.width))
             metric = "inference img/s @2048x1024 DLA-34 (1 GPU)"
         hbm, mfma = dcn_roofline(summary)
+        chbm, cmfma = conv_roofline(summary)
+        if mfma is None:                                   # Hourglass: no DCN, the 3x3 convolution dominates
+            hbm, mfma = chbm, cmfma
         line.update({
             "metric": metric, "unit": "img/s",
             "value": world * args.steps / t, "ms_per_step": 1e3 * t / args.steps,
@@ -559,7 +602,11 @@ def main(argv=None):
             # (157.3 TFLOP/s / 8 TB/s = 19.7 FLOP/B): the fp32 matrix pipe is the binding roofline,
             # the HBM fraction of the same launch is reported beside it
             "roofline": mfma, "roofline_hbm": hbm,
-            "dcn_layers_ms": {"%d->%d@%dx%d" % k[1:5]: round(v["avg_ms"], 4) for k, v in summary.items()},
+            "roofline_conv3x3": cmfma, "roofline_conv3x3_hbm": chbm,
+            "dcn_layers_ms": {"%d->%d@%dx%d" % k[1:5]: round(v["avg_ms"], 4) for k, v in summary.items()
+                              if k[0].startswith("dcn")},
+            "conv3x3_ms_per_image": round(sum(v["avg_ms"] * v["launches"] for k, v in summary.items()
+                                              if k[0].startswith("conv3x3")) / max(1, args.steps), 4),
         })
         if world == 1 and cfg == "2":
             if not args.no_offset_points:

@@ -15,6 +15,7 @@ namespace {
 
 constexpr int SEG = 8192;          // floats per workgroup segment (256 threads x 8 float4)
 constexpr int THREADS = 256;
+constexpr int NV = SEG / (THREADS * 4);   // float4 per thread per segment
 
 struct BnDims {
   int B, C;
@@ -42,10 +43,18 @@ __global__ __launch_bounds__(THREADS) void bn_stats_kernel(const float* __restri
   const long long i0 = (long long)seg * SEG, i1 = min(d.HW, i0 + SEG);
   float s = 0.f, q = 0.f;
   if ((d.HW & 3) == 0) {
-    for (long long i = i0 + threadIdx.x * 4; i < i1; i += THREADS * 4) {
-      const f32x4 v = *reinterpret_cast<const f32x4*>(p + i);
-      s += (v[0] + v[1]) + (v[2] + v[3]);
-      q += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+    // all NV float4 loads of the segment are issued before the first use (a rolled loop waits out one HBM
+    // latency per iteration)
+    f32x4 v[NV];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const long long i = i0 + (k * THREADS + threadIdx.x) * 4;
+      v[k] = i < i1 ? *reinterpret_cast<const f32x4*>(p + i) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      s += (v[k][0] + v[k][1]) + (v[k][2] + v[k][3]);
+      q += (v[k][0] * v[k][0] + v[k][1] * v[k][1]) + (v[k][2] * v[k][2] + v[k][3] * v[k][3]);
     }
   } else {
     for (long long i = i0 + threadIdx.x; i < i1; i += THREADS) { const float v = p[i]; s += v; q += v * v; }
@@ -96,18 +105,24 @@ __global__ __launch_bounds__(THREADS) void bn_apply_kernel(const float* __restri
   const float sh = (bias ? bias[c] : 0.f) - mean[c] * sc;
   const long long i0 = (long long)seg * SEG, i1 = min(d.HW, i0 + SEG);
   if ((d.HW & 3) == 0) {
-    for (long long i = i0 + threadIdx.x * 4; i < i1; i += THREADS * 4) {
-      f32x4 v = *reinterpret_cast<const f32x4*>(x + base + i);
+    f32x4 xv[NV], rv[NV];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) v[k] = v[k] * sc + sh;
-      if (res) {
-        const f32x4 r = *reinterpret_cast<const f32x4*>(res + base + i);
+    for (int j = 0; j < NV; ++j) {
+      const long long i = i0 + (j * THREADS + threadIdx.x) * 4;
+      const bool ok = i < i1;
+      xv[j] = ok ? *reinterpret_cast<const f32x4*>(x + base + i) : f32x4{0.f, 0.f, 0.f, 0.f};
+      rv[j] = (ok && res) ? *reinterpret_cast<const f32x4*>(res + base + i) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
 #pragma unroll
-        for (int k = 0; k < 4; ++k) v[k] += r[k];
-      }
-      if (relu) {
+    for (int j = 0; j < NV; ++j) {
+      const long long i = i0 + (j * THREADS + threadIdx.x) * 4;
+      if (i >= i1) continue;
+      f32x4 v = xv[j];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.f);
+      for (int k = 0; k < 4; ++k) {
+        v[k] = v[k] * sc + sh;
+        if (res) v[k] += rv[j][k];
+        if (relu) v[k] = fmaxf(v[k], 0.f);
       }
       *reinterpret_cast<f32x4*>(y + base + i) = v;
     }
@@ -133,16 +148,23 @@ __global__ __launch_bounds__(THREADS) void bn_bwd_reduce_kernel(const float* __r
   const long long i0 = (long long)seg * SEG, i1 = min(d.HW, i0 + SEG);
   float s = 0.f, q = 0.f;
   if ((d.HW & 3) == 0) {
-    for (long long i = i0 + threadIdx.x * 4; i < i1; i += THREADS * 4) {
-      const f32x4 xv = *reinterpret_cast<const f32x4*>(x + base + i);
-      f32x4 g = *reinterpret_cast<const f32x4*>(gy + base + i);
-      if (relu) {
-        const f32x4 yv = *reinterpret_cast<const f32x4*>(y + base + i);
+    f32x4 xv[NV], gv[NV], yv[NV];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) g[k] = yv[k] > 0.f ? g[k] : 0.f;
+    for (int j = 0; j < NV; ++j) {
+      const long long i = i0 + (j * THREADS + threadIdx.x) * 4;
+      const bool ok = i < i1;
+      xv[j] = ok ? *reinterpret_cast<const f32x4*>(x + base + i) : f32x4{0.f, 0.f, 0.f, 0.f};
+      gv[j] = ok ? *reinterpret_cast<const f32x4*>(gy + base + i) : f32x4{0.f, 0.f, 0.f, 0.f};
+      yv[j] = (ok && relu) ? *reinterpret_cast<const f32x4*>(y + base + i) : f32x4{1.f, 1.f, 1.f, 1.f};
+    }
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float g = yv[j][k] > 0.f ? gv[j][k] : 0.f;
+        s += g;
+        q += g * ((xv[j][k] - m) * is);
       }
-#pragma unroll
-      for (int k = 0; k < 4; ++k) { s += g[k]; q += g[k] * ((xv[k] - m) * is); }
     }
   } else {
     for (long long i = i0 + threadIdx.x; i < i1; i += THREADS) {
@@ -189,17 +211,25 @@ __global__ __launch_bounds__(THREADS) void bn_bwd_apply_kernel(
   const float k0 = (w ? w[c] : 1.f) * is, db = coef[2 * c], dg = coef[2 * c + 1];
   const long long i0 = (long long)seg * SEG, i1 = min(d.HW, i0 + SEG);
   if ((d.HW & 3) == 0) {
-    for (long long i = i0 + threadIdx.x * 4; i < i1; i += THREADS * 4) {
-      const f32x4 xv = *reinterpret_cast<const f32x4*>(x + base + i);
-      f32x4 g = *reinterpret_cast<const f32x4*>(gy + base + i);
-      if (relu) {
-        const f32x4 yv = *reinterpret_cast<const f32x4*>(y + base + i);
+    f32x4 xv[NV], gv[NV], yv[NV];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) g[k] = yv[k] > 0.f ? g[k] : 0.f;
+    for (int j = 0; j < NV; ++j) {
+      const long long i = i0 + (j * THREADS + threadIdx.x) * 4;
+      const bool ok = i < i1;
+      xv[j] = ok ? *reinterpret_cast<const f32x4*>(x + base + i) : f32x4{0.f, 0.f, 0.f, 0.f};
+      gv[j] = ok ? *reinterpret_cast<const f32x4*>(gy + base + i) : f32x4{0.f, 0.f, 0.f, 0.f};
+      yv[j] = (ok && relu) ? *reinterpret_cast<const f32x4*>(y + base + i) : f32x4{1.f, 1.f, 1.f, 1.f};
+    }
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const long long i = i0 + (j * THREADS + threadIdx.x) * 4;
+      if (i >= i1) continue;
+      f32x4 g, o;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        g[k] = yv[j][k] > 0.f ? gv[j][k] : 0.f;
+        o[k] = k0 * (g[k] - db - (xv[j][k] - m) * is * dg);
       }
-      f32x4 o;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) o[k] = k0 * (g[k] - db - (xv[k] - m) * is * dg);
       *reinterpret_cast<f32x4*>(gx + base + i) = o;
       if (gres) *reinterpret_cast<f32x4*>(gres + base + i) = g;
     }

@@ -33,23 +33,22 @@ constexpr int TW = 32;              // tile width (pixels)
 constexpr int LW = TW + 2;          // staged width
 constexpr unsigned OOB = 0xFFFFFFF0u;
 
-// wp[((((cot * nchunk + chunk) * 9 + tap) * MT + mt) * 2 + hl) * 64 + lane][j] =
-//   half(hl) of Wsrc[m = (cot * MT + mt) * 16 + (lane & 15)][k = chunk * 32 + 8 (lane >> 4) + j][tap]
+// wp[(((ct * nchunk + chunk) * 9 + tap) * 2 + hl) * 64 + lane][j] =
+//   half(hl) of Wsrc[m = ct * 16 + (lane & 15)][k = chunk * 32 + 8 (lane >> 4) + j][tap]        (ct: 16-row tile)
 // Wsrc = W ([M][K][9]) or, transposed (input gradient): Wsrc[m][k][tap] = W[k][m][8 - tap] with W = [K][M][9].
+// Rows past M (the tile count is rounded up to a multiple of 4) and k past K are zero.
 __global__ __launch_bounds__(256) void conv_mfma_wperm_kernel(const float* __restrict__ w, bf16x8* __restrict__ wp, int M,
-                                                              int K, int MT, int nchunk, int transposed, int total) {
+                                                              int K, int nchunk, int transposed, int total) {
   const int e = blockIdx.x * 256 + threadIdx.x;
   if (e >= total) return;
   const int lane = e & 63;
   int r = e >> 6;
   const int hl = r & 1;
   r >>= 1;
-  const int mt = r % MT;
-  r /= MT;
   const int tap = r % 9;
   r /= 9;
-  const int chunk = r % nchunk, cot = r / nchunk;
-  const int m = (cot * MT + mt) * 16 + (lane & 15);
+  const int chunk = r % nchunk, ct = r / nchunk;
+  const int m = ct * 16 + (lane & 15);
   bf16x8 o;
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
@@ -104,12 +103,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(CvArgs a) {
 #pragma unroll
     for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const bf16x8* wq = a.wp + (long long)cot * a.nchunk * 9 * MT * 2 * 64 + lane;
+  const long long tstride = (long long)a.nchunk * 9 * 2 * 64;          // fragments per 16-row weight tile
+  const bf16x8* wq = a.wp + (long long)cot * MT * tstride + lane;
   bf16x8 af[MT][2];
 #pragma unroll
   for (int m = 0; m < MT; ++m) {
-    af[m][0] = wq[(m * 2 + 0) * 64];
-    af[m][1] = wq[(m * 2 + 1) * 64];
+    af[m][0] = wq[m * tstride];
+    af[m][1] = wq[m * tstride + 64];
   }
 
   // B fragment base of this lane: channel group g, wave's first row, col c (tile origin is (-1, -1))
@@ -156,11 +156,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(CvArgs a) {
       bf16x8 an[MT][2];
       {
         const bool last = tap == 8 && chunk == a.nchunk - 1;
-        const bf16x8* nq = wq + (long long)((chunk * 9 + tap + (last ? 0 : 1)) * MT * 2) * 64;
+        const bf16x8* nq = wq + (long long)((chunk * 9 + tap + (last ? 0 : 1)) * 2) * 64;
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
-          an[m][0] = nq[(m * 2 + 0) * 64];
-          an[m][1] = nq[(m * 2 + 1) * 64];
+          an[m][0] = nq[m * tstride];
+          an[m][1] = nq[m * tstride + 64];
         }
       }
       bf16x8 bh[NT], bl[NT];
@@ -212,7 +212,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(CvArgs a) {
   }
 }
 
-int mt_for(int Cout) { return Cout <= 32 ? 2 : 4; }
+int tiles16(int Cout) { return (Cout + 63) / 64 * 4; }             // 16-row weight tiles, padded to whole groups of 4
 
 }  // namespace
 
@@ -225,8 +225,7 @@ int cp_conv3x3_mfma_supported(int32_t Cin, int32_t Cout, int32_t H, int32_t W) {
 }
 
 size_t cp_conv3x3_mfma_weight_bytes(int32_t Cin, int32_t Cout) {
-  const int MT = mt_for(Cout), ncot = (Cout + 16 * MT - 1) / (16 * MT), nchunk = (Cin + KC - 1) / KC;
-  return (size_t)ncot * nchunk * 9 * MT * 2 * 64 * 16;
+  return (size_t)tiles16(Cout) * ((Cin + KC - 1) / KC) * 9 * 2 * 64 * 16;
 }
 
 // weight: [Cout][Cin][3][3] (transposed = 0), or -- for the input gradient of a convolution whose weight is
@@ -235,10 +234,10 @@ int cp_conv3x3_mfma_prepare(const float* weight, int32_t Cin, int32_t Cout, int3
                             void* stream) {
   hipStream_t st = (hipStream_t)stream;
   CP_CHECK_ARG(weight && wperm && Cin >= 1 && Cout >= 1);
-  const int MT = mt_for(Cout), ncot = (Cout + 16 * MT - 1) / (16 * MT), nchunk = (Cin + KC - 1) / KC;
-  const int total = ncot * nchunk * 9 * MT * 2 * 64;
+  const int nchunk = (Cin + KC - 1) / KC;
+  const int total = tiles16(Cout) * nchunk * 9 * 2 * 64;
   hipLaunchKernelGGL(conv_mfma_wperm_kernel, dim3((total + 255) / 256), dim3(256), 0, st, weight, (bf16x8*)wperm, Cout,
-                     Cin, MT, nchunk, transposed, total);
+                     Cin, nchunk, transposed, total);
   return cp_launch_status();
 }
 
@@ -247,7 +246,6 @@ int cp_conv3x3_mfma_forward(const float* x, const void* wperm, const float* bias
   hipStream_t st = (hipStream_t)stream;
   CP_CHECK_ARG(x && wperm && out && B >= 1);
   if (!cp_conv3x3_mfma_supported(Cin, Cout, H, W)) return CP_EUNSUPPORTED;
-  const int MT = mt_for(Cout);
   CvArgs a;
   a.x = x;
   a.wp = (const bf16x8*)wperm;
@@ -259,16 +257,21 @@ int cp_conv3x3_mfma_forward(const float* x, const void* wperm, const float* bias
   a.W = W;
   a.Cout = Cout;
   a.nchunk = (Cin + KC - 1) / KC;
-  a.ncot = (Cout + 16 * MT - 1) / (16 * MT);
   a.tiles_x = (W + TW - 1) / TW;
   a.relu = relu;
-  if (MT == 4) {
-    const int tiles = a.tiles_x * ((H + 7) / 8);
-    hipLaunchKernelGGL((conv3x3_mfma_kernel<4, 2>), dim3(tiles * a.ncot, B), dim3(256), 0, st, a);
-  } else {
-    const int tiles = a.tiles_x * ((H + 15) / 16);
-    hipLaunchKernelGGL((conv3x3_mfma_kernel<2, 4>), dim3(tiles * a.ncot, B), dim3(256), 0, st, a);
-  }
+  // Tile variant by how many workgroups it yields (the chip wants >= 2 per CU): 64 output channels x 8 rows is the
+  // most efficient (fewest fragment bytes per MFMA); layers that cannot fill the CUs with it take 32 channels
+  // x 8 rows, then 32 x 4 rows.  <= 32 output channels: 32 x 16 rows, then the same narrow forms.
+  auto wgs = [&](int mt, int th) { return (long long)a.tiles_x * ((H + th - 1) / th) * B * ((Cout + 16 * mt - 1) / (16 * mt)); };
+  auto launch = [&](auto kernel, int mt, int th) {
+    a.ncot = (Cout + 16 * mt - 1) / (16 * mt);
+    const int tiles = a.tiles_x * ((H + th - 1) / th);
+    hipLaunchKernelGGL(kernel, dim3(tiles * a.ncot, B), dim3(256), 0, st, a);
+  };
+  if (Cout > 32 && wgs(4, 8) >= 448) launch(conv3x3_mfma_kernel<4, 2>, 4, 8);
+  else if (Cout <= 32 && wgs(2, 16) >= 448) launch(conv3x3_mfma_kernel<2, 4>, 2, 16);
+  else if (wgs(2, 8) >= 320) launch(conv3x3_mfma_kernel<2, 2>, 2, 8);
+  else launch(conv3x3_mfma_kernel<2, 1>, 2, 4);
   return cp_launch_status();
 }
 

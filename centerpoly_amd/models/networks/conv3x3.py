@@ -19,13 +19,12 @@ from ... import _C
 _ENABLED = os.environ.get("CP_CONV_MFMA", "1") != "0"
 _WGRAD = os.environ.get("CP_CONV_MFMA_WGRAD", "1") != "0"
 MIN_CIN = 24                 # the contraction steps over 32 input channels: fewer would mostly multiply zeros
-MIN_WORKGROUPS = 96          # below this the launch cannot fill the 256 CUs and the library is faster
+MIN_WORKGROUPS = 128         # (of the narrowest tile form) below this the launch cannot fill the 256 CUs
 
 
 def _workgroups(B, cout, H, W):
-    rows = 16 if cout <= 32 else 8
-    per_wg = 32 if cout <= 32 else 64
-    return B * ((W + 31) // 32) * ((H + rows - 1) // rows) * ((cout + per_wg - 1) // per_wg)
+    """Workgroups of the narrowest tile form the library picks for small layers: 32 channels x 4 rows x 32 px."""
+    return B * ((W + 31) // 32) * ((H + 3) // 4) * ((cout + 31) // 32)
 
 
 def usable_shape(x, cout):
@@ -55,9 +54,12 @@ def _prepare(weight, cin, cout, transposed):
 def _launch(x, wp, bias, residual, cout, relu):
     B, cin, H, W = x.shape
     out = torch.empty((B, cout, H, W), dtype=torch.float32, device=x.device)
+    end = _C.kernel_timer.start(("conv3x3_fwd", cin, cout, H, W, B)) if _C.kernel_timer is not None else None
     _C.check(_C.lib().cp_conv3x3_mfma_forward(_C.ptr(x), _C.ptr(wp), _C.ptr(bias), _C.ptr(residual), _C.ptr(out),
                                               B, cin, H, W, cout, 1 if relu else 0, _C.stream()),
              "cp_conv3x3_mfma_forward")
+    if end is not None:
+        end.record()
     return out
 
 
@@ -89,24 +91,37 @@ class _Conv3x3Fn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, go):
         x, weight = ctx.saved_tensors
-        go = go.contiguous()
-        cout, cin = weight.shape[0], weight.shape[1]
-        gx = gw = None
-        if ctx.needs_input_grad[0]:
-            B, _, H, W = x.shape
-            if cout >= MIN_CIN and _C.lib().cp_conv3x3_mfma_supported(cout, cin, H, W):
-                gx = _launch(go, _prepare(weight, cout, cin, True), None, None, cin, False)
-            else:
-                gx = torch.nn.grad.conv2d_input(x.shape, weight, go, padding=1)
-        if ctx.needs_input_grad[1]:
-            B, _, H, W = x.shape
-            if _WGRAD and _C.lib().cp_conv3x3_mfma_wgrad_supported(cin, cout, H, W):
-                gw = torch.zeros_like(weight)
-                _C.check(_C.lib().cp_conv3x3_mfma_wgrad(_C.ptr(x), _C.ptr(go), _C.ptr(gw), B, cin, H, W, cout,
-                                                        _C.stream()), "cp_conv3x3_mfma_wgrad")
-            else:
-                gw = torch.nn.grad.conv2d_weight(x, weight.shape, go, padding=1)
-        return gx, gw
+        return grads(x, weight, go.contiguous(), ctx.needs_input_grad[0], ctx.needs_input_grad[1],
+                     min_k=MIN_CIN)
+
+
+def mfma_enabled():
+    return _ENABLED
+
+
+def grads(x, weight, go, want_x=True, want_w=True, min_k=1):
+    """(grad_x, grad_weight) of a 3x3 / stride 1 / pad 1 convolution from grad_out: the MFMA kernels where they
+    take the shape (the input gradient contracts over Cout: below `min_k` output channels it goes to the library)."""
+    L = _C.lib()
+    cout, cin = weight.shape[0], weight.shape[1]
+    B, _, H, W = x.shape
+    gx = gw = None
+    if want_x:
+        if cout >= min_k and L.cp_conv3x3_mfma_supported(cout, cin, H, W):
+            gx = _launch(go, _prepare(weight, cout, cin, True), None, None, cin, False)
+        else:
+            gx = torch.nn.grad.conv2d_input(x.shape, weight, go, padding=1)
+    if want_w:
+        if _WGRAD and L.cp_conv3x3_mfma_wgrad_supported(cin, cout, H, W):
+            gw = torch.zeros_like(weight)
+            end = _C.kernel_timer.start(("conv3x3_wgrad", cin, cout, H, W, B)) if _C.kernel_timer is not None else None
+            _C.check(L.cp_conv3x3_mfma_wgrad(_C.ptr(x), _C.ptr(go), _C.ptr(gw), B, cin, H, W, cout, _C.stream()),
+                     "cp_conv3x3_mfma_wgrad")
+            if end is not None:
+                end.record()
+        else:
+            gw = torch.nn.grad.conv2d_weight(x, weight.shape, go, padding=1)
+    return gx, gw
 
 
 def conv_raw(conv, x):

@@ -19,6 +19,7 @@ from torch import nn
 
 from ... import _C
 from .DCNv2.dcn_v2 import DCN, conv_bias
+from . import conv3x3
 from .conv3x3 import conv3x3_infer, conv_raw
 
 BN_MOMENTUM = 0.1
@@ -93,6 +94,11 @@ class _DirectConvFn(torch.autograd.Function):
         x, weight = ctx.saved_tensors
         stride, pad = ctx.cfg
         go = go.contiguous()
+        if weight.shape[2] == 3 and stride == 1 and pad == 1 and conv3x3.mfma_enabled():
+            # level0 (16 -> 16 at full resolution): both gradients through the split-bf16 MFMA kernels -- most of
+            # their 32 / 64-channel tiles multiply zeros, but the layer is bandwidth-bound and the library's
+            # NHWC round trip (transposes + implicit GEMM) costs 5x more
+            return conv3x3.grads(x, weight, go, ctx.needs_input_grad[0], ctx.needs_input_grad[1]) + (None, None)
         gx = torch.nn.grad.conv2d_input(x.shape, weight, go, stride=stride, padding=pad) \
             if ctx.needs_input_grad[0] else None
         gw = torch.nn.grad.conv2d_weight(x, weight.shape, go, stride=stride, padding=pad) \

@@ -1027,5 +1027,10 @@ def test_direct_conv_training_function_gradients():
         y2 = conv(x2)
         y2.backward(go)
         torch.testing.assert_close(y1, y2, rtol=1e-4, atol=1e-5)
-        torch.testing.assert_close(x1.grad, x2.grad, rtol=1e-4, atol=1e-5)
-        torch.testing.assert_close(gw1, conv.weight.grad, rtol=1e-4, atol=1e-4)
+        # (3x3 / stride 1: both gradients come from the split-bf16 kernels -- ~2^-16 per product, max-norm bound)
+        mfma = k == 3 and stride == 1
+        for got, ref in ((x1.grad, x2.grad), (gw1, conv.weight.grad)):
+            if mfma:
+                assert (got - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()
+            else:
+                torch.testing.assert_close(got, ref, rtol=1e-4, atol=1e-4)
