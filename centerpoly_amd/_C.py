@@ -140,15 +140,25 @@ def workspace(nbytes, device):
     return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
 
 
+class _NoEvent(object):
+    def record(self):
+        pass
+
+
 class KernelTimer(object):
     """Optional per-launch HIP-event timing on torch's current stream (where every kernel of
     this library is launched).  bench.py enables it around the timed region to get the
-    dominant kernel's average launch duration; disabled (None) it costs nothing."""
+    dominant kernel's average launch duration; disabled (None) it costs nothing.
+    `watch`: a set of keys -- only those launches get events (an event pair costs a few
+    microseconds of stream time, which adds up over ~50 launches per step)."""
 
-    def __init__(self):
+    def __init__(self, watch=None):
         self.records = {}
+        self.watch = watch
 
     def start(self, key):
+        if self.watch is not None and key not in self.watch:
+            return _NoEvent()
         ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
         self.records.setdefault(key, []).append(ev)
         ev[0].record()
