@@ -30,23 +30,23 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int KC = 32;              // input channels per k-step
 constexpr int TW = 32;              // tile width (pixels)
-constexpr int LW = TW + 2;          // staged width
 constexpr unsigned OOB = 0xFFFFFFF0u;
 
-// wp[(((ct * nchunk + chunk) * 9 + tap) * 2 + hl) * 64 + lane][j] =
+// wp[(((ct * nchunk + chunk) * taps + tap) * 2 + hl) * 64 + lane][j] =
 //   half(hl) of Wsrc[m = ct * 16 + (lane & 15)][k = chunk * 32 + 8 (lane >> 4) + j][tap]        (ct: 16-row tile)
-// Wsrc = W ([M][K][9]) or, transposed (input gradient): Wsrc[m][k][tap] = W[k][m][8 - tap] with W = [K][M][9].
+// taps = 9 (3x3) or 1 (1x1).  Wsrc = W ([M][K][taps]) or, transposed (input gradient):
+// Wsrc[m][k][tap] = W[k][m][taps - 1 - tap] with W = [K][M][taps].
 // Rows past M (the tile count is rounded up to a multiple of 4) and k past K are zero.
 __global__ __launch_bounds__(256) void conv_mfma_wperm_kernel(const float* __restrict__ w, bf16x8* __restrict__ wp, int M,
-                                                              int K, int nchunk, int transposed, int total) {
+                                                              int K, int nchunk, int taps, int transposed, int total) {
   const int e = blockIdx.x * 256 + threadIdx.x;
   if (e >= total) return;
   const int lane = e & 63;
   int r = e >> 6;
   const int hl = r & 1;
   r >>= 1;
-  const int tap = r % 9;
-  r /= 9;
+  const int tap = r % taps;
+  r /= taps;
   const int chunk = r % nchunk, ct = r / nchunk;
   const int m = ct * 16 + (lane & 15);
   bf16x8 o;
@@ -54,15 +54,18 @@ __global__ __launch_bounds__(256) void conv_mfma_wperm_kernel(const float* __res
   for (int j = 0; j < 8; ++j) {
     const int k = chunk * KC + 8 * (lane >> 4) + j;
     float v = 0.f;
-    if (m < M && k < K) v = transposed ? w[((long long)k * M + m) * 9 + (8 - tap)] : w[((long long)m * K + k) * 9 + tap];
+    if (m < M && k < K)
+      v = transposed ? w[((long long)k * M + m) * taps + (taps - 1 - tap)] : w[((long long)m * K + k) * taps + tap];
     const __bf16 h = (__bf16)v;
     o[j] = hl ? (__bf16)(v - (float)h) : h;
   }
   wp[e] = o;
 }
 
+constexpr int MAXSRC = 4;
 struct CvArgs {
-  const float* x;
+  const float* xsrc[MAXSRC];   // the input is the channel concatenation of up to 4 tensors [B][csrc[i]][H][W]
+  int csrc[MAXSRC];            // (several sources: each a multiple of 32 channels, so no k-step straddles two)
   const bf16x8* wp;
   const float* bias;      // [Cout] or null
   const float* res;       // same shape as out, or null
@@ -70,9 +73,10 @@ struct CvArgs {
   int Cin, H, W, Cout, nchunk, ncot, tiles_x, relu;
 };
 
-template <int MT, int RW>
-__global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(CvArgs a) {
-  constexpr int TH = 4 * RW, LH = TH + 2, NT = 2 * RW, PLANE = 4 * LH * LW;      // PLANE: fragments per half
+template <int MT, int RW, int TAPS>
+__global__ __launch_bounds__(256, 2) void conv_mfma_kernel(CvArgs a) {
+  constexpr int HALO = TAPS == 9 ? 1 : 0, LW = TW + 2 * HALO;
+  constexpr int TH = 4 * RW, LH = TH + 2 * HALO, NT = 2 * RW, PLANE = 4 * LH * LW;   // PLANE: fragments per half
   constexpr int UNITS = PLANE, ITERS = (UNITS + 255) / 256, SB = ITERS <= 6 ? ITERS : 5;
   __shared__ bf16x8 Xs[2 * PLANE];
 
@@ -81,17 +85,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(CvArgs a) {
   const int x0 = (tile % a.tiles_x) * TW, y0 = (tile / a.tiles_x) * TH, b = blockIdx.y;
   const int HW = a.H * a.W;
 
-  const float* xb = a.x + (long long)b * a.Cin * HW;
-  const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(xb), 0, (int)((unsigned)a.Cin * (unsigned)HW * 4u), 0x00020000);
-
   // staging units of this thread: (channel group, row, col) -> byte offset of channel 0 of the group, or OOB
   unsigned soff[ITERS];
 #pragma unroll
   for (int i = 0; i < ITERS; ++i) {
     const int u = tid + i * 256;
     const int col = u % LW, r = (u / LW) % LH, cg = u / (LW * LH);
-    const int gy = y0 - 1 + r, gx = x0 - 1 + col;
+    const int gy = y0 - HALO + r, gx = x0 - HALO + col;
     const bool ok = u < UNITS && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
     soff[i] = ok ? ((unsigned)(cg * 8) * (unsigned)HW + (unsigned)(gy * a.W + gx)) * 4u : OOB;
   }
@@ -103,7 +103,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(CvArgs a) {
 #pragma unroll
     for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const long long tstride = (long long)a.nchunk * 9 * 2 * 64;          // fragments per 16-row weight tile
+  const long long tstride = (long long)a.nchunk * TAPS * 2 * 64;       // fragments per 16-row weight tile
   const bf16x8* wq = a.wp + (long long)cot * MT * tstride + lane;
   bf16x8 af[MT][2];
 #pragma unroll
@@ -112,13 +112,21 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(CvArgs a) {
     af[m][1] = wq[m * tstride + 64];
   }
 
-  // B fragment base of this lane: channel group g, wave's first row, col c (tile origin is (-1, -1))
+  // B fragment base of this lane: channel group g, wave's first row, col c (tile origin is (-HALO, -HALO))
   const int bbase = (g * LH + wid * RW) * LW + c;
 
+  int src = 0, src_c0 = 0;                                    // source tensor of the current chunk, its first channel
   for (int chunk = 0; chunk < a.nchunk; ++chunk) {
     __syncthreads();                                          // the previous chunk's fragments have been read
     {
-      const unsigned cb = (unsigned)chunk * KC * cstep;
+      while (src + 1 < MAXSRC && chunk * KC >= src_c0 + a.csrc[src] && a.csrc[src + 1] > 0) {
+        src_c0 += a.csrc[src];
+        ++src;
+      }
+      const int cs = a.csrc[src];
+      const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<float*>(a.xsrc[src] + (long long)b * cs * HW), 0, (int)((unsigned)cs * (unsigned)HW * 4u), 0x00020000);
+      const unsigned cb = (unsigned)(chunk * KC - src_c0) * cstep;
 #pragma unroll
       for (int i0 = 0; i0 < ITERS; i0 += SB) {                // batches of SB units: 8 SB loads in flight per thread
         float v[SB][8];
@@ -150,13 +158,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(CvArgs a) {
     __syncthreads();
 
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
+    for (int tap = 0; tap < TAPS; ++tap) {
       const int dy = tap / 3, dx = tap % 3;
       // next tap's (or next chunk's first) weight fragments; past the end: re-read the last (harmless, in bounds)
       bf16x8 an[MT][2];
       {
-        const bool last = tap == 8 && chunk == a.nchunk - 1;
-        const bf16x8* nq = wq + (long long)((chunk * 9 + tap + (last ? 0 : 1)) * 2) * 64;
+        const bool last = tap == TAPS - 1 && chunk == a.nchunk - 1;
+        const bf16x8* nq = wq + (long long)((chunk * TAPS + tap + (last ? 0 : 1)) * 2) * 64;
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
           an[m][0] = nq[m * tstride];
@@ -224,30 +232,51 @@ int cp_conv3x3_mfma_supported(int32_t Cin, int32_t Cout, int32_t H, int32_t W) {
          (long long)(Cin + KC) * H * W * 4 < 0xFFFFFFF0ll;
 }
 
-size_t cp_conv3x3_mfma_weight_bytes(int32_t Cin, int32_t Cout) {
-  return (size_t)tiles16(Cout) * ((Cin + KC - 1) / KC) * 9 * 2 * 64 * 16;
+size_t cp_conv_mfma_weight_bytes(int32_t Cin, int32_t Cout, int32_t taps) {
+  return (size_t)tiles16(Cout) * ((Cin + KC - 1) / KC) * taps * 2 * 64 * 16;
 }
 
-// weight: [Cout][Cin][3][3] (transposed = 0), or -- for the input gradient of a convolution whose weight is
-// [K][M][3][3] -- the same tensor read as Wsrc[m][k][tap] = W[k][m][8 - tap] (transposed = 1; Cin := K, Cout := M).
-int cp_conv3x3_mfma_prepare(const float* weight, int32_t Cin, int32_t Cout, int32_t transposed, void* wperm,
-                            void* stream) {
+size_t cp_conv3x3_mfma_weight_bytes(int32_t Cin, int32_t Cout) { return cp_conv_mfma_weight_bytes(Cin, Cout, 9); }
+
+// weight: [Cout][Cin][k][k], k*k = taps (transposed = 0), or -- for the input gradient of a convolution whose weight
+// is [K][M][k][k] -- the same tensor read as Wsrc[m][k][tap] = W[k][m][taps - 1 - tap] (transposed = 1; Cin := K,
+// Cout := M).
+int cp_conv_mfma_prepare(const float* weight, int32_t Cin, int32_t Cout, int32_t taps, int32_t transposed, void* wperm,
+                         void* stream) {
   hipStream_t st = (hipStream_t)stream;
-  CP_CHECK_ARG(weight && wperm && Cin >= 1 && Cout >= 1);
+  CP_CHECK_ARG(weight && wperm && Cin >= 1 && Cout >= 1 && (taps == 1 || taps == 9));
   const int nchunk = (Cin + KC - 1) / KC;
-  const int total = tiles16(Cout) * nchunk * 9 * 2 * 64;
+  const int total = tiles16(Cout) * nchunk * taps * 2 * 64;
   hipLaunchKernelGGL(conv_mfma_wperm_kernel, dim3((total + 255) / 256), dim3(256), 0, st, weight, (bf16x8*)wperm, Cout,
-                     Cin, nchunk, transposed, total);
+                     Cin, nchunk, taps, transposed, total);
   return cp_launch_status();
 }
 
-int cp_conv3x3_mfma_forward(const float* x, const void* wperm, const float* bias, const float* residual, float* out,
-                            int32_t B, int32_t Cin, int32_t H, int32_t W, int32_t Cout, int32_t relu, void* stream) {
+int cp_conv3x3_mfma_prepare(const float* weight, int32_t Cin, int32_t Cout, int32_t transposed, void* wperm,
+                            void* stream) {
+  return cp_conv_mfma_prepare(weight, Cin, Cout, 9, transposed, wperm, stream);
+}
+
+// The input is the channel concatenation of `nsrc` (1..4) tensors xs[i] = [B][cs[i]][H][W] (what the reference
+// builds with torch.cat before a 1x1 `Root` convolution, pose_dla_dcn.py:148-166) -- read in place, never
+// materialised.  With several sources every cs[i] must be a multiple of 32.  taps = 9: 3x3 / pad 1; taps = 1: 1x1.
+int cp_conv_mfma_forward(const float* const* xs, const int32_t* cs, int32_t nsrc, const void* wperm, const float* bias,
+                         const float* residual, float* out, int32_t B, int32_t H, int32_t W, int32_t Cout,
+                         int32_t taps, int32_t relu, void* stream) {
   hipStream_t st = (hipStream_t)stream;
-  CP_CHECK_ARG(x && wperm && out && B >= 1);
-  if (!cp_conv3x3_mfma_supported(Cin, Cout, H, W)) return CP_EUNSUPPORTED;
+  CP_CHECK_ARG(xs && cs && wperm && out && B >= 1 && nsrc >= 1 && nsrc <= MAXSRC && (taps == 1 || taps == 9));
   CvArgs a;
-  a.x = x;
+  int Cin = 0;
+  for (int i = 0; i < MAXSRC; ++i) {
+    a.xsrc[i] = i < nsrc ? xs[i] : nullptr;
+    a.csrc[i] = i < nsrc ? cs[i] : 0;
+    if (i < nsrc) {
+      CP_CHECK_ARG(xs[i] && cs[i] >= 1);
+      if (nsrc > 1 && cs[i] % KC != 0) return CP_EUNSUPPORTED;
+      if (!cp_conv3x3_mfma_supported(cs[i], Cout, H, W)) return CP_EUNSUPPORTED;
+      Cin += cs[i];
+    }
+  }
   a.wp = (const bf16x8*)wperm;
   a.bias = bias;
   a.res = residual;
@@ -268,11 +297,26 @@ int cp_conv3x3_mfma_forward(const float* x, const void* wperm, const float* bias
     const int tiles = a.tiles_x * ((H + th - 1) / th);
     hipLaunchKernelGGL(kernel, dim3(tiles * a.ncot, B), dim3(256), 0, st, a);
   };
-  if (Cout > 32 && wgs(4, 8) >= 448) launch(conv3x3_mfma_kernel<4, 2>, 4, 8);
-  else if (Cout <= 32 && wgs(2, 16) >= 448) launch(conv3x3_mfma_kernel<2, 4>, 2, 16);
-  else if (wgs(2, 8) >= 320) launch(conv3x3_mfma_kernel<2, 2>, 2, 8);
-  else launch(conv3x3_mfma_kernel<2, 1>, 2, 4);
+  if (taps == 9) {
+    if (Cout > 32 && wgs(4, 8) >= 448) launch(conv_mfma_kernel<4, 2, 9>, 4, 8);
+    else if (Cout <= 32 && wgs(2, 16) >= 448) launch(conv_mfma_kernel<2, 4, 9>, 2, 16);
+    else if (wgs(2, 8) >= 320) launch(conv_mfma_kernel<2, 2, 9>, 2, 8);
+    else launch(conv_mfma_kernel<2, 1, 9>, 2, 4);
+  } else {                                          // 1x1: bandwidth-bound, the grid only has to fill the chip
+    if (Cout > 32 && wgs(4, 8) >= 448) launch(conv_mfma_kernel<4, 2, 1>, 4, 8);
+    else if (wgs(2, 8) >= 320) launch(conv_mfma_kernel<2, 2, 1>, 2, 8);
+    else launch(conv_mfma_kernel<2, 1, 1>, 2, 4);
+  }
   return cp_launch_status();
+}
+
+int cp_conv3x3_mfma_forward(const float* x, const void* wperm, const float* bias, const float* residual, float* out,
+                            int32_t B, int32_t Cin, int32_t H, int32_t W, int32_t Cout, int32_t relu, void* stream) {
+  CP_CHECK_ARG(x);
+  if (!cp_conv3x3_mfma_supported(Cin, Cout, H, W)) return CP_EUNSUPPORTED;
+  const float* xs[1] = {x};
+  const int32_t cs[1] = {Cin};
+  return cp_conv_mfma_forward(xs, cs, 1, wperm, bias, residual, out, B, H, W, Cout, 9, relu, stream);
 }
 
 }  // extern "C"

@@ -63,19 +63,53 @@ def _launch(x, wp, bias, residual, cout, relu):
     return out
 
 
-def conv3x3_infer(x, owner, w, bias=None, residual=None, relu=False, conv=None, key="_mfma_wperm"):
-    """Inference: 3x3 / stride 1 / pad 1 convolution with the (folded) weight `w`, + bias + residual + ReLU in
-    the kernel's epilogue.  The permuted weights are cached on `owner` (under `key`) for as long as `w` is the
-    same, unmodified tensor.  `conv`, when given, is the module whose geometry must be the kernel's.
-    Returns None when the shape is not the kernel's."""
-    ok = usable(conv, x) if conv is not None else (tuple(w.shape[2:]) == (3, 3) and usable_shape(x, w.shape[0]))
-    if not ok or w.shape[1] != x.shape[1] or (residual is not None and not residual.is_contiguous()):
+def conv_infer(xs, owner, w, bias=None, residual=None, relu=False, conv=None, key="_mfma_wperm"):
+    """Inference: 3x3 / pad 1 or 1x1 convolution (stride 1) of the channel concatenation of `xs` -- read in place,
+    no torch.cat -- with the (folded) weight `w`, + bias + residual + ReLU in the kernel's epilogue.  The permuted
+    weights are cached on `owner` (under `key`) for as long as `w` is the same, unmodified tensor.  `conv`, when
+    given, is the module whose geometry must be the kernel's.  Returns None when the shape is not the kernel's."""
+    k = tuple(w.shape[2:])
+    if not _ENABLED or k not in ((1, 1), (3, 3)):
         return None
+    if conv is not None and not (conv.stride == (1, 1) and conv.padding == (k[0] // 2, k[0] // 2)
+                                 and conv.dilation == (1, 1) and conv.groups == 1 and conv.padding_mode == "zeros"):
+        return None
+    x0 = xs[0]
+    if not all(x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[0] == x0.shape[0]
+               and x.shape[2:] == x0.shape[2:] for x in xs) or len(xs) > 4:
+        return None
+    cs = [x.shape[1] for x in xs]
+    cin, cout = sum(cs), w.shape[0]
+    B, _, H, W = x0.shape
+    L = _C.lib()
+    if cin != w.shape[1] or cin < MIN_CIN or (len(xs) > 1 and any(c % 32 for c in cs)) \
+            or not all(L.cp_conv3x3_mfma_supported(c, cout, H, W) for c in cs) \
+            or _workgroups(B, cout, H, W) < MIN_WORKGROUPS or (residual is not None and not residual.is_contiguous()):
+        return None
+    taps = k[0] * k[1]
     cache = owner.__dict__.get(key)
     if cache is None or cache[0] is not w or cache[1] != w._version:
-        cache = (w, w._version, _prepare(w.contiguous(), w.shape[1], w.shape[0], False))
+        wp = torch.empty(L.cp_conv_mfma_weight_bytes(cin, cout, taps), dtype=torch.uint8, device=w.device)
+        _C.check(L.cp_conv_mfma_prepare(_C.ptr(w.contiguous()), cin, cout, taps, 0, _C.ptr(wp), _C.stream()),
+                 "cp_conv_mfma_prepare")
+        cache = (w, w._version, wp)
         owner.__dict__[key] = cache
-    return _launch(x.contiguous(), cache[2], bias, residual, w.shape[0], relu)
+    xs = [x.contiguous() for x in xs]
+    out = torch.empty((B, cout, H, W), dtype=torch.float32, device=x0.device)
+    ptrs = (_C.c_void_p * len(xs))(*[x.data_ptr() for x in xs])
+    chans = (_C.c_int32 * len(xs))(*cs)
+    tag = "conv3x3_fwd" if taps == 9 else "conv1x1_fwd"
+    end = _C.kernel_timer.start((tag, cin, cout, H, W, B)) if _C.kernel_timer is not None else None
+    _C.check(L.cp_conv_mfma_forward(ptrs, chans, len(xs), _C.ptr(cache[2]), _C.ptr(bias), _C.ptr(residual), _C.ptr(out),
+                                    B, H, W, cout, taps, 1 if relu else 0, _C.stream()), "cp_conv_mfma_forward")
+    if end is not None:
+        end.record()
+    return out
+
+
+def conv3x3_infer(x, owner, w, bias=None, residual=None, relu=False, conv=None, key="_mfma_wperm"):
+    """conv_infer for one input tensor (kept for the call sites that predate the 1x1 / multi-source form)."""
+    return conv_infer([x], owner, w, bias, residual, relu, conv=conv, key=key)
 
 
 class _Conv3x3Fn(torch.autograd.Function):

@@ -20,7 +20,7 @@ from torch import nn
 from ... import _C
 from .DCNv2.dcn_v2 import DCN, conv_bias
 from . import conv3x3
-from .conv3x3 import conv3x3_infer, conv_raw
+from .conv3x3 import conv3x3_infer, conv_infer, conv_raw
 
 BN_MOMENTUM = 0.1
 
@@ -276,8 +276,12 @@ class Root(nn.Module):
 
     def forward(self, *xs):
         if _use_folded(self):
-            return _conv_folded(torch.cat(xs, 1), self.conv, self._folded, relu=True,
-                                residual=xs[0] if self.residual else None)
+            res = xs[0] if self.residual else None
+            if xs[0].is_cuda:                       # 1x1 over the inputs in place: no concatenated copy
+                y = conv_infer(list(xs), self.conv, self._folded[0], self._folded[1], res, True, conv=self.conv)
+                if y is not None:
+                    return y
+            return _conv_folded(torch.cat(xs, 1), self.conv, self._folded, relu=True, residual=res)
         return bn_act(self.bn, self.conv(torch.cat(xs, 1)), relu=True,
                       residual=xs[0] if self.residual else None)
 

@@ -184,6 +184,17 @@ int cp_conv3x3_mfma_prepare(const float* weight, int32_t Cin, int32_t Cout, int3
 int cp_conv3x3_mfma_forward(const float* x, const void* wperm, const float* bias, const float* residual, float* out,
                             int32_t B, int32_t Cin, int32_t H, int32_t W, int32_t Cout, int32_t relu, void* stream);
 
+/* General form of the above: taps = 9 (3x3 / pad 1) or 1 (1x1), and the input given as the channel concatenation of
+ * nsrc (1..4) tensors xs[i] = [B][cs[i]][H][W] read in place -- the torch.cat of `Root.forward`
+ * (src/lib/models/networks/pose_dla_dcn.py:148-166) is never materialised.  With nsrc > 1 every cs[i] must be a
+ * multiple of 32.  Weights prepared by cp_conv_mfma_prepare with the same taps over Cin = sum cs[i]. */
+size_t cp_conv_mfma_weight_bytes(int32_t Cin, int32_t Cout, int32_t taps);
+int cp_conv_mfma_prepare(const float* weight, int32_t Cin, int32_t Cout, int32_t taps, int32_t transposed, void* wperm,
+                         void* stream);
+int cp_conv_mfma_forward(const float* const* xs, const int32_t* cs, int32_t nsrc, const void* wperm, const float* bias,
+                         const float* residual, float* out, int32_t B, int32_t H, int32_t W, int32_t Cout,
+                         int32_t taps, int32_t relu, void* stream);
+
 /* Weight gradient of the same convolution, same arithmetic (what the reference gets from cuDNN's backward-filter):
  *   gw[co][ci][ky][kx] += sum_{b,y,x} go[b][co][y][x] * x[b][ci][y - 1 + ky][x - 1 + kx]
  * gw [Cout][Cin][3][3] is ACCUMULATED into (float atomics: zero it first; the summation order varies from run to

@@ -169,3 +169,42 @@ def test_wgrad_refuses_unaligned_width():
     assert not L.cp_conv3x3_mfma_wgrad_supported(64, 64, 8, 30)
     x, go, gw = _t("ux", (1, 64, 8, 30)), _t("ugo", (1, 64, 8, 30)), torch.zeros((64, 64, 3, 3), device=DEV)
     assert L.cp_conv3x3_mfma_wgrad(P(x), P(go), P(gw), 1, 64, 8, 30, 64, _C.stream()) == -2
+
+
+def _conv_multi(xs, w, bias=None, residual=None, relu=False):
+    L = _C.lib()
+    B, _, H, W = xs[0].shape
+    cs = [x.shape[1] for x in xs]
+    cin, cout, taps = sum(cs), w.shape[0], w.shape[2] * w.shape[3]
+    wp = torch.empty(L.cp_conv_mfma_weight_bytes(cin, cout, taps), dtype=torch.uint8, device=DEV)
+    _C.check(L.cp_conv_mfma_prepare(P(w), cin, cout, taps, 0, P(wp), _C.stream()), "prepare")
+    out = torch.full((B, cout, H, W), float("nan"), device=DEV)
+    ptrs = (ctypes.c_void_p * len(xs))(*[x.data_ptr() for x in xs])
+    chans = (ctypes.c_int32 * len(xs))(*cs)
+    rc = L.cp_conv_mfma_forward(ptrs, chans, len(xs), P(wp), P(bias), P(residual), P(out), B, H, W, cout, taps,
+                                1 if relu else 0, _C.stream())
+    return rc, out
+
+
+# (channels of the sources, Cout, k, H, W): the Root layers of DLA-34 (two to four inputs), a 1x1 projection,
+# a 3x3 over two sources, ragged single-source 1x1
+MULTI = [((64, 64), 64, 1, 40, 72), ((128, 128, 64), 128, 1, 17, 33), ((256, 256, 128, 64), 256, 1, 8, 32),
+         ((64,), 128, 1, 24, 80), ((32, 64), 48, 3, 12, 40), ((200,), 27, 1, 9, 31)]
+
+
+@pytest.mark.parametrize("case", MULTI, ids=[str(m[0]) + "->%d k%d" % (m[1], m[2]) for m in MULTI])
+def test_concatenated_sources_and_1x1(case):
+    cs, co, k, H, W = case
+    xs = [_t("ms%d_%d" % (i, c), (2, c, H, W)) for i, c in enumerate(cs)]
+    w = _t("msw%s" % (case,), (co, sum(cs), k, k), 0.05)
+    bias, res = _t("msb", (co,)), _t("msr", (2, co, H, W))
+    rc, out = _conv_multi(xs, w, bias, res, True)
+    assert rc == 0
+    ref = F.relu(F.conv2d(torch.cat(xs, 1).double(), w.double(), bias.double(), padding=k // 2) + res.double())
+    assert torch.isfinite(out).all() and _rel(out, ref) <= TOL
+
+
+def test_multi_source_needs_whole_k_steps():
+    xs = [_t("bad0", (1, 48, 8, 32)), _t("bad1", (1, 64, 8, 32))]
+    rc, _ = _conv_multi(xs, _t("badw", (32, 112, 1, 1)))
+    assert rc == -2                                       # CP_EUNSUPPORTED: 48 is not a multiple of 32
