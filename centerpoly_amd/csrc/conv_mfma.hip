@@ -73,14 +73,22 @@ struct CvArgs {
   int Cin, H, W, Cout, nchunk, ncot, tiles_x, relu;
 };
 
-template <int MT, int RW, int TAPS>
-__global__ __launch_bounds__(256, 2) void conv_mfma_kernel(CvArgs a) {
+// KS > 1 (deep, small layers whose grid cannot fill the chip -- one wave per SIMD exposes every load latency): the
+// workgroup is KS groups of 4 waves, group q takes the channel chunks q, q + KS, ... of the SAME output tile through
+// its own staged tile, so the sequential chunk steps drop KS-fold; the partial accumulators meet in LDS in a fixed
+// order (deterministic) and group 0 runs the epilogue.
+template <int MT, int RW, int TAPS, int KS = 1>
+__global__ __launch_bounds__(256 * KS, KS > 1 ? 4 : 2) void conv_mfma_kernel(CvArgs a) {
   constexpr int HALO = TAPS == 9 ? 1 : 0, LW = TW + 2 * HALO;
   constexpr int TH = 4 * RW, LH = TH + 2 * HALO, NT = 2 * RW, PLANE = 4 * LH * LW;   // PLANE: fragments per half
   constexpr int UNITS = PLANE, ITERS = (UNITS + 255) / 256, SB = ITERS <= 6 ? ITERS : 5;
-  __shared__ bf16x8 Xs[2 * PLANE];
+  constexpr int RED = (KS - 1) * 256 * MT * NT;                                     // f32x4 slots of the reduction
+  constexpr int XS_F = KS * 2 * PLANE;
+  __shared__ bf16x8 Xall[XS_F > RED ? XS_F : RED];
 
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, g = lane >> 4, c = lane & 15;
+  const int grp = __builtin_amdgcn_readfirstlane(threadIdx.x >> 8);
+  bf16x8* Xs = Xall + grp * 2 * PLANE;
+  const int tid = threadIdx.x & 255, lane = tid & 63, wid = tid >> 6, g = lane >> 4, c = lane & 15;
   const int cot = blockIdx.x % a.ncot, tile = blockIdx.x / a.ncot;
   const int x0 = (tile % a.tiles_x) * TW, y0 = (tile / a.tiles_x) * TH, b = blockIdx.y;
   const int HW = a.H * a.W;
@@ -106,19 +114,23 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(CvArgs a) {
   const long long tstride = (long long)a.nchunk * TAPS * 2 * 64;       // fragments per 16-row weight tile
   const bf16x8* wq = a.wp + (long long)cot * MT * tstride + lane;
   bf16x8 af[MT][2];
+  {
+    const bf16x8* fq = wq + (long long)(min(grp, a.nchunk - 1) * TAPS * 2) * 64;     // this group's first chunk
 #pragma unroll
-  for (int m = 0; m < MT; ++m) {
-    af[m][0] = wq[m * tstride];
-    af[m][1] = wq[m * tstride + 64];
+    for (int m = 0; m < MT; ++m) {
+      af[m][0] = fq[m * tstride];
+      af[m][1] = fq[m * tstride + 64];
+    }
   }
 
   // B fragment base of this lane: channel group g, wave's first row, col c (tile origin is (-HALO, -HALO))
   const int bbase = (g * LH + wid * RW) * LW + c;
 
   int src = 0, src_c0 = 0;                                    // source tensor of the current chunk, its first channel
-  for (int chunk = 0; chunk < a.nchunk; ++chunk) {
+  for (int chunk = grp; chunk - grp < a.nchunk; chunk += KS) {
+    const bool active = chunk < a.nchunk;                     // (wave-uniform; every wave takes every barrier)
     __syncthreads();                                          // the previous chunk's fragments have been read
-    {
+    if (active) {
       while (src + 1 < MAXSRC && chunk * KC >= src_c0 + a.csrc[src] && a.csrc[src + 1] > 0) {
         src_c0 += a.csrc[src];
         ++src;
@@ -156,15 +168,17 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(CvArgs a) {
       }
     }
     __syncthreads();
+    if (!active) continue;
 
 #pragma unroll
     for (int tap = 0; tap < TAPS; ++tap) {
       const int dy = tap / 3, dx = tap % 3;
-      // next tap's (or next chunk's first) weight fragments; past the end: re-read the last (harmless, in bounds)
+      // next tap's (or this group's next chunk's first) weight fragments; past the end: re-read the last
       bf16x8 an[MT][2];
       {
-        const bool last = tap == TAPS - 1 && chunk == a.nchunk - 1;
-        const bf16x8* nq = wq + (long long)((chunk * TAPS + tap + (last ? 0 : 1)) * 2) * 64;
+        const int nfrag = tap < TAPS - 1 ? chunk * TAPS + tap + 1
+                                         : (chunk + KS < a.nchunk ? (chunk + KS) * TAPS : chunk * TAPS + tap);
+        const bf16x8* nq = wq + (long long)(nfrag * 2) * 64;
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
           an[m][0] = nq[m * tstride];
@@ -193,6 +207,25 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(CvArgs a) {
       }
       __builtin_amdgcn_sched_barrier(0);                      // keep the taps' fragment reads from piling up
     }
+  }
+
+  if (KS > 1) {                                               // partial sums of groups 1 .. KS-1 -> LDS -> group 0
+    __syncthreads();
+    f32x4* red = reinterpret_cast<f32x4*>(Xall);
+    if (grp > 0) {
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) red[((grp - 1) * MT * NT + m * NT + n) * 256 + tid] = acc[m][n];
+    }
+    __syncthreads();
+    if (grp > 0) return;
+#pragma unroll
+    for (int q = 1; q < KS; ++q)
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[m][n] += red[((q - 1) * MT * NT + m * NT + n) * 256 + tid];
   }
 
   // epilogue: D[row = 4 g + r (co)][col = c (pixel)]
@@ -292,20 +325,24 @@ int cp_conv_mfma_forward(const float* const* xs, const int32_t* cs, int32_t nsrc
   // most efficient (fewest fragment bytes per MFMA); layers that cannot fill the CUs with it take 32 channels
   // x 8 rows, then 32 x 4 rows.  <= 32 output channels: 32 x 16 rows, then the same narrow forms.
   auto wgs = [&](int mt, int th) { return (long long)a.tiles_x * ((H + th - 1) / th) * B * ((Cout + 16 * mt - 1) / (16 * mt)); };
-  auto launch = [&](auto kernel, int mt, int th) {
+  auto launch = [&](auto kernel, int mt, int th, int ks) {
     a.ncot = (Cout + 16 * mt - 1) / (16 * mt);
     const int tiles = a.tiles_x * ((H + th - 1) / th);
-    hipLaunchKernelGGL(kernel, dim3(tiles * a.ncot, B), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(kernel, dim3(tiles * a.ncot, B), dim3(256 * ks), 0, st, a);
   };
   if (taps == 9) {
-    if (Cout > 32 && wgs(4, 8) >= 448) launch(conv_mfma_kernel<4, 2, 9>, 4, 8);
-    else if (Cout <= 32 && wgs(2, 16) >= 448) launch(conv_mfma_kernel<2, 4, 9>, 2, 16);
-    else if (wgs(2, 8) >= 320) launch(conv_mfma_kernel<2, 2, 9>, 2, 8);
-    else launch(conv_mfma_kernel<2, 1, 9>, 2, 4);
+    if (Cout > 32 && wgs(4, 8) >= 448) launch(conv_mfma_kernel<4, 2, 9>, 4, 8, 1);
+    else if (Cout <= 32 && wgs(2, 16) >= 448) launch(conv_mfma_kernel<2, 4, 9>, 2, 16, 1);
+    else if (wgs(2, 8) >= 320) launch(conv_mfma_kernel<2, 2, 9>, 2, 8, 1);
+    else if (wgs(2, 4) < 384 && a.nchunk >= 8) launch(conv_mfma_kernel<2, 1, 9, 4>, 2, 4, 4);   // in-workgroup K split
+    else if (wgs(2, 4) < 768 && a.nchunk >= 4) launch(conv_mfma_kernel<2, 1, 9, 2>, 2, 4, 2);
+    else launch(conv_mfma_kernel<2, 1, 9>, 2, 4, 1);
   } else {                                          // 1x1: bandwidth-bound, the grid only has to fill the chip
-    if (Cout > 32 && wgs(4, 8) >= 448) launch(conv_mfma_kernel<4, 2, 1>, 4, 8);
-    else if (wgs(2, 8) >= 320) launch(conv_mfma_kernel<2, 2, 1>, 2, 8);
-    else launch(conv_mfma_kernel<2, 1, 1>, 2, 4);
+    if (Cout > 32 && wgs(4, 8) >= 448) launch(conv_mfma_kernel<4, 2, 1>, 4, 8, 1);
+    else if (wgs(2, 8) >= 320) launch(conv_mfma_kernel<2, 2, 1>, 2, 8, 1);
+    else if (wgs(2, 4) < 384 && a.nchunk >= 8) launch(conv_mfma_kernel<2, 1, 1, 4>, 2, 4, 4);
+    else if (wgs(2, 4) < 768 && a.nchunk >= 4) launch(conv_mfma_kernel<2, 1, 1, 2>, 2, 4, 2);
+    else launch(conv_mfma_kernel<2, 1, 1>, 2, 4, 1);
   }
   return cp_launch_status();
 }
