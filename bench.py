@@ -244,8 +244,8 @@ def dcn_roofline(summary, tag="dcn_fwd"):
               "launches": summary[key]["launches"]}
     hbm = dict(common, bound="hbm", achieved=alg_bytes / avg_s / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
                frac=alg_bytes / avg_s / 1e9 / HBM_PEAK_GBS, algorithmic_bytes_per_launch=alg_bytes)
-    if tag == "dcn_bwd_data" and os.environ.get("CP_DCN_BWD_F32", "0") != "1":
-        mfma = split_bf16_roofline(common, alg_flops, avg_s)   # this kernel contracts in split-bf16 x3
+    if tag in ("dcn_bwd_data", "dcn_bwd_weight") and os.environ.get("CP_DCN_BWD_F32", "0") != "1" and w % 4 == 0:
+        mfma = split_bf16_roofline(common, alg_flops, avg_s)   # the backward kernels contract in split-bf16 x3
     else:
         mfma = dict(common, bound="mfma", achieved=alg_flops / avg_s / 1e12, peak=MFMA_F32_PEAK_TF, unit="TFLOP/s",
                     frac=alg_flops / avg_s / 1e12 / MFMA_F32_PEAK_TF, algorithmic_flops_per_launch=alg_flops)
