@@ -186,27 +186,30 @@ def timed(fn, steps, warmup, world, tag=""):
     return t
 
 
-def kernel_revision():
-    """Content hash of the DCNv2 forward kernel source: PMC traffic files are only trusted for the
-    kernel revision they were taken on."""
+CONV_SOURCES = ("conv_mfma.hip", "cp_common.h")
+
+
+def kernel_revision(sources=("dcn_fwd.hip", "cp_common.h")):
+    """Content hash of a kernel's sources (default: the DCNv2 forward kernel): PMC traffic files are only
+    trusted for the kernel revision they were taken on."""
     h = hashlib.sha256()
-    for f in ("dcn_fwd.hip", "cp_common.h"):
+    for f in sources:
         with open(os.path.join(ROOT, "centerpoly_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]
 
 
-def measured_traffic(cin, cout, h, w, nb):
-    """HBM bytes per launch of the dominant DCNv2 forward launch from the committed rocprofv3 PMC
+def measured_traffic(cin, cout, h, w, nb, prof_name="dcn_fwd_pmc.json", sources=("dcn_fwd.hip", "cp_common.h")):
+    """HBM bytes per launch of a kernel family's dominant launch from the committed rocprofv3 PMC
     passes -- only when those passes were taken on bench.py's own tensors at the CURRENT kernel
-    revision (tools/pmc_bench_traffic.py writes the file); otherwise null."""
-    prof = os.path.join(ROOT, "profiles", "dcn_fwd_pmc.json")
+    revision (tools/pmc_bench_traffic.py writes the files); otherwise null."""
+    prof = os.path.join(ROOT, "profiles", prof_name)
     try:
         with open(prof) as fh:
             d = json.load(fh)
     except (OSError, ValueError):
         return None, "no PMC file"
-    if d.get("kernel_rev") != kernel_revision():
+    if d.get("kernel_rev") != kernel_revision(sources):
         return None, "PMC passes are from another kernel revision (%s): not reported" % d.get("kernel_rev")
     if d.get("inputs") != "bench.py infer leg":
         return None, "PMC passes were not taken on the bench inputs"
@@ -275,7 +278,10 @@ def conv_roofline(summary, tag="conv3x3_fwd"):
     alg_flops = 2.0 * 9 * cin * cout * h * w * nb
     alg_bytes = 4.0 * (nb * (cin + cout) * h * w + 9 * cin * cout)
     name = "conv3x3 weight gradient" if tag == "conv3x3_wgrad" else "conv3x3 forward / input gradient"
-    common = {"traffic": None, "traffic_source": "not measured for this kernel",
+    traffic, traffic_src = (None, "not measured for this kernel")
+    if tag == "conv3x3_fwd":
+        traffic, traffic_src = measured_traffic(cin, cout, h, w, nb, "conv_mfma_pmc.json", CONV_SOURCES)
+    common = {"traffic": traffic, "traffic_source": traffic_src,
               "kernel": "%s %d->%d @%dx%d" % (name, cin, cout, h, w) + (" x%d images" % nb if nb != 1 else ""),
               "avg_launch_us": avg_s * 1e6, "launches": summary[key]["launches"]}
     hbm = dict(common, bound="hbm", achieved=alg_bytes / avg_s / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",

@@ -87,7 +87,7 @@ def test_traffic_is_null_for_a_stale_kernel_revision(tmp_path, monkeypatch):
     prof = tmp_path / "profiles"
     prof.mkdir()
     monkeypatch.setattr(bench, "ROOT", str(tmp_path))
-    monkeypatch.setattr(bench, "kernel_revision", lambda: "abc")
+    monkeypatch.setattr(bench, "kernel_revision", lambda *a: "abc")
     (prof / "dcn_fwd_pmc.json").write_text(json.dumps(
         {"kernel_rev": "old", "inputs": "bench.py infer leg", "layers": {"1x64x64x256x512": 1.0}}))
     assert bench.measured_traffic(64, 64, 256, 512, 1)[0] is None

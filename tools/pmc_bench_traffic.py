@@ -16,11 +16,16 @@ import bench
 SHAPES = {524288: (1, 64, 64, 256, 512)}
 
 
-def avg(dirname, counter):
+# the fused heads' convolution of the same step (conv_mfma_kernel<4, 2, 9, 1>: 512 tiles x 16 output-channel tiles
+# x 256 threads), the dominant launch of the split-bf16 convolution at inference
+CONV_SHAPES = {512 * 16 * 256: (1, 64, 1024, 256, 512)}
+
+
+def avg(dirname, counter, match="dcn_fwd"):
     vals = {}
     for f in glob.glob(os.path.join(dirname, "**", "*counter_collection.csv"), recursive=True):
         for row in csv.DictReader(open(f)):
-            if "dcn_fwd" in row["Kernel_Name"] and row["Counter_Name"] == counter:
+            if match in row["Kernel_Name"] and row["Counter_Name"] == counter:
                 vals.setdefault(int(row["Grid_Size"]), []).append(float(row["Counter_Value"]))
     return {g: (sum(v) / len(v), len(v)) for g, v in vals.items()}
 
@@ -42,3 +47,22 @@ out = {"kernel_rev": bench.kernel_revision(), "inputs": "bench.py infer leg",
        "layers": layers, "_raw": raw}
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 print(json.dumps(out))
+
+
+# ---- the same two passes reduced for the MFMA convolution (wide coalesced streams: the doubling applies) ----
+if len(sys.argv) > 4:
+    fetch, write = avg(sys.argv[1], "FETCH_SIZE", "conv_mfma_kernel<4, 2, 9"), avg(sys.argv[2], "WRITE_SIZE", "conv_mfma_kernel<4, 2, 9")
+    layers, raw = {}, {}
+    for grid, shape in CONV_SHAPES.items():
+        if grid in fetch and grid in write:
+            f, n = fetch[grid]
+            w, _ = write[grid]
+            layers["%dx%dx%dx%dx%d" % shape] = (2.0 * f + w) * 1024.0
+            raw["%dx%dx%dx%dx%d" % shape] = {"FETCH_SIZE_KB_avg": f, "WRITE_SIZE_KB_avg": w, "launches": n}
+    out = {"kernel_rev": bench.kernel_revision(bench.CONV_SOURCES), "inputs": "bench.py infer leg",
+           "command": out["command"],
+           "correction": "traffic = (2*FETCH_SIZE + WRITE_SIZE)*1024 bytes (gfx950: FETCH_SIZE reports half of a wide "
+                         "coalesced stream's bytes, WRITE_SIZE is exact)",
+           "layers": layers, "_raw": raw}
+    json.dump(out, open(sys.argv[4], "w"), indent=1)
+    print(json.dumps(out))
