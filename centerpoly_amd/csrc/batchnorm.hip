@@ -35,6 +35,23 @@ __device__ __forceinline__ void block_reduce2(double& a, double& b) {
   b = red[1][0] + red[1][1] + red[1][2] + red[1][3];
 }
 
+// Sum of a channel's B * nseg partial pairs, by every workgroup of that channel in the same order (so all of them --
+// and the backward pass, which reads what workgroup (0, c, 0) stores -- use bit-identical statistics).  Replaces the
+// one-thread-per-channel finalize launches (two per BatchNorm and step, ~10 us each) by a 4 KB L2-resident read and
+// one block reduction inside the apply passes.
+__device__ __forceinline__ void channel_sums(const double* __restrict__ partial, const BnDims& d, int c, double& s,
+                                             double& q) {
+  const int n = d.B * d.nseg;
+  const double* p = partial + 2 * (long long)c * n;
+  s = 0;
+  q = 0;
+  for (int i = threadIdx.x; i < n; i += THREADS) {
+    s += p[2 * i];
+    q += p[2 * i + 1];
+  }
+  block_reduce2(s, q);
+}
+
 // grid = (nseg, C, B): partial[(c * B + b) * nseg + seg] = (sum, sum of squares)
 __global__ __launch_bounds__(THREADS) void bn_stats_kernel(const float* __restrict__ x, BnDims d,
                                                            double* __restrict__ partial) {
@@ -68,41 +85,38 @@ __global__ __launch_bounds__(THREADS) void bn_stats_kernel(const float* __restri
   }
 }
 
-// one thread per channel: mean / invstd, running statistics
-__global__ void bn_stats_finalize_kernel(const double* __restrict__ partial, BnDims d, float eps,
-                                         float momentum, float* __restrict__ mean,
-                                         float* __restrict__ invstd, float* __restrict__ running_mean,
-                                         float* __restrict__ running_var) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= d.C) return;
-  const int n = d.B * d.nseg;
-  double s = 0, q = 0;
-  for (int i = 0; i < n; ++i) { s += partial[2 * ((long long)c * n + i)]; q += partial[2 * ((long long)c * n + i) + 1]; }
-  const double N = (double)d.B * (double)d.HW;
-  const double m = s / N;
-  double var = q / N - m * m;
-  if (var < 0) var = 0;
-  mean[c] = (float)m;
-  invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
-  if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)m;
-  if (running_var) {
-    const double unbiased = N > 1 ? var * N / (N - 1) : var;
-    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
-  }
-}
-
-// y = act((x - mean) * invstd * w + b (+ residual))
+// (the statistics are finalised here from the partial sums: mean / invstd, and by workgroup (0, c, 0) the saved and
+//  running statistics)
 __global__ __launch_bounds__(THREADS) void bn_apply_kernel(const float* __restrict__ x,
                                                            const float* __restrict__ res,
                                                            float* __restrict__ y, BnDims d,
-                                                           const float* __restrict__ mean,
-                                                           const float* __restrict__ invstd,
+                                                           const double* __restrict__ partial, float eps,
+                                                           float momentum, float* __restrict__ mean,
+                                                           float* __restrict__ invstd,
+                                                           float* __restrict__ running_mean,
+                                                           float* __restrict__ running_var,
                                                            const float* __restrict__ w,
                                                            const float* __restrict__ bias, int relu) {
   const int seg = blockIdx.x, c = blockIdx.y, b = blockIdx.z;
   const long long base = ((long long)b * d.C + c) * d.HW;
-  const float sc = invstd[c] * (w ? w[c] : 1.f);
-  const float sh = (bias ? bias[c] : 0.f) - mean[c] * sc;
+  double ds, dq;
+  channel_sums(partial, d, c, ds, dq);
+  const double N = (double)d.B * (double)d.HW;
+  const double m = ds / N;
+  double var = dq / N - m * m;
+  if (var < 0) var = 0;
+  const float meanf = (float)m, invf = (float)(1.0 / sqrt(var + (double)eps));
+  if (seg == 0 && b == 0 && threadIdx.x == 0) {
+    mean[c] = meanf;
+    invstd[c] = invf;
+    if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * meanf;
+    if (running_var) {
+      const double unbiased = N > 1 ? var * N / (N - 1) : var;
+      running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+    }
+  }
+  const float sc = invf * (w ? w[c] : 1.f);
+  const float sh = (bias ? bias[c] : 0.f) - meanf * sc;
   const long long i0 = (long long)seg * SEG, i1 = min(d.HW, i0 + SEG);
   if ((d.HW & 3) == 0) {
     f32x4 xv[NV], rv[NV];
@@ -183,32 +197,23 @@ __global__ __launch_bounds__(THREADS) void bn_bwd_reduce_kernel(const float* __r
   }
 }
 
-// one thread per channel: grad_bias, grad_weight (+= into the outputs), and the two per-channel
-// coefficients the apply pass needs, stored after the partials: coef[2c] = dbeta/N, coef[2c+1] = dgamma/N
-__global__ void bn_bwd_finalize_kernel(const double* __restrict__ partial, BnDims d,
-                                       float* __restrict__ grad_w, float* __restrict__ grad_b,
-                                       float* __restrict__ coef) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= d.C) return;
-  const int n = d.B * d.nseg;
-  double s = 0, q = 0;
-  for (int i = 0; i < n; ++i) { s += partial[2 * ((long long)c * n + i)]; q += partial[2 * ((long long)c * n + i) + 1]; }
-  const double N = (double)d.B * (double)d.HW;
-  if (grad_b) grad_b[c] = (float)s;
-  if (grad_w) grad_w[c] = (float)q;
-  coef[2 * c] = (float)(s / N);
-  coef[2 * c + 1] = (float)(q / N);
-}
-
 // dx = w * invstd * (g - dbeta/N - xhat * dgamma/N);  dres = g
 __global__ __launch_bounds__(THREADS) void bn_bwd_apply_kernel(
     const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ gy, BnDims d,
     const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ w,
-    const float* __restrict__ coef, int relu, float* __restrict__ gx, float* __restrict__ gres) {
+    const double* __restrict__ partial, float* __restrict__ grad_w, float* __restrict__ grad_b, int relu,
+    float* __restrict__ gx, float* __restrict__ gres) {
   const int seg = blockIdx.x, c = blockIdx.y, b = blockIdx.z;
   const long long base = ((long long)b * d.C + c) * d.HW;
   const float m = mean[c], is = invstd[c];
-  const float k0 = (w ? w[c] : 1.f) * is, db = coef[2 * c], dg = coef[2 * c + 1];
+  double ds, dq;                                     // (sum g, sum g * xhat) of the channel, finalised here
+  channel_sums(partial, d, c, ds, dq);
+  if (seg == 0 && b == 0 && threadIdx.x == 0) {
+    if (grad_b) grad_b[c] = (float)ds;
+    if (grad_w) grad_w[c] = (float)dq;
+  }
+  const double N = (double)d.B * (double)d.HW;
+  const float k0 = (w ? w[c] : 1.f) * is, db = (float)(ds / N), dg = (float)(dq / N);
   const long long i0 = (long long)seg * SEG, i1 = min(d.HW, i0 + SEG);
   if ((d.HW & 3) == 0) {
     f32x4 xv[NV], gv[NV], yv[NV];
@@ -274,10 +279,8 @@ extern "C" int cp_bn_act_forward_train(const float* x, const float* weight, cons
   double* partial = (double*)workspace;
   const dim3 grid(d.nseg, C, B);
   hipLaunchKernelGGL(bn_stats_kernel, grid, dim3(THREADS), 0, st, x, d, partial);
-  hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, st, partial, d, eps,
-                     momentum, save_mean, save_invstd, running_mean, running_var);
-  hipLaunchKernelGGL(bn_apply_kernel, grid, dim3(THREADS), 0, st, x, residual, y, d, save_mean,
-                     save_invstd, weight, bias, relu);
+  hipLaunchKernelGGL(bn_apply_kernel, grid, dim3(THREADS), 0, st, x, residual, y, d, partial, eps, momentum,
+                     save_mean, save_invstd, running_mean, running_var, weight, bias, relu);
   return cp_launch_status();
 }
 
@@ -294,13 +297,10 @@ extern "C" int cp_bn_act_backward(const float* x, const float* y, const float* g
   if (workspace_bytes < cp_bn_workspace_bytes(B, C, HW)) return CP_EWORKSPACE;
   hipStream_t st = (hipStream_t)stream;
   double* partial = (double*)workspace;
-  float* coef = (float*)(partial + (size_t)C * B * d.nseg * 2);
   const dim3 grid(d.nseg, C, B);
   hipLaunchKernelGGL(bn_bwd_reduce_kernel, grid, dim3(THREADS), 0, st, x, y, grad_y, d, save_mean,
                      save_invstd, relu, partial);
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, st, partial, d,
-                     grad_weight, grad_bias, coef);
   hipLaunchKernelGGL(bn_bwd_apply_kernel, grid, dim3(THREADS), 0, st, x, y, grad_y, d, save_mean,
-                     save_invstd, weight, coef, relu, grad_x, grad_residual);
+                     save_invstd, weight, partial, grad_weight, grad_bias, relu, grad_x, grad_residual);
   return cp_launch_status();
 }
