@@ -67,6 +67,8 @@ _SIGNATURES = {
     "cp_polydet_targets_workspace_bytes": (c_size_t, [POINTER(TargetShape)]),
     "cp_polydet_targets": (c_int32, [POINTER(TargetShape)] + [_P] * 19 + [_P, c_size_t, _P]),
     "cp_conv_direct_supported": (c_int32, [c_int32] * 5),
+    "cp_conv_direct_wgrad_supported": (c_int32, [c_int32] * 5),
+    "cp_conv_direct_wgrad": (c_int32, [_P, _P, _P] + [c_int32] * 8 + [_P]),
     "cp_conv_direct_forward": (c_int32, [_P, _P, _P, _P] + [c_int32] * 9 + [_P]),
     "cp_conv3x3_mfma_supported": (c_int32, [c_int32] * 4),
     "cp_conv3x3_mfma_weight_bytes": (c_size_t, [c_int32] * 2),

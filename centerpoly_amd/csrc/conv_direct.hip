@@ -281,3 +281,177 @@ extern "C" int cp_conv_direct_forward(const float* x, const float* w, const floa
   }
   return cp_launch_status();
 }
+
+// =====================================================================================================================
+// Weight gradient of the same full-resolution, low-channel layers (what the reference gets from cuDNN's
+// backward-filter for `base_layer` / `level0` / `level1`, pose_dla_dcn.py:236-246,266-276):
+//   gw[co][ci][ky][kx] += sum_{b, y, x} go[b][co][y][x] * in[b][ci][S y + ky - pad][S x + kx - pad]
+// The library ran these as NHWC implicit GEMMs behind two layout transposes of full-resolution maps (stem 1.8 ms,
+// level1 0.9 ms per B = 4 step); the layers are a few GFLOP over 100-300 MB, i.e. bandwidth-sized.
+// Contraction over PIXELS on the exact f32 MFMA (v_mfma_f32_16x16x4_f32): D[co][n] += A[co][px] * B[px][n] with
+// n = (ci, ky, kx) flattened -- 147 / 144 columns = 10 / 9 fragments of 16.  One workgroup walks pixel tiles of
+// 8 x 32 (stride 2: 4 x 32) outputs (grid-stride); per tile grad_out ([co][256 px], pitch 260) and the input's halo region
+// ([ci][S*8 + K - S rows][S*32 + K - S cols]) are staged in LDS; wave w owns the k-steps w, w + 4, ... (4 pixels each)
+// for ALL column fragments: per k-step one A read per 16 output channels and, per fragment, ONE B read at
+// (the lane's column offset ci*plane + ky*pitch + kx) + S * (pixel offset) -- no column tile is ever built.  The
+// partial gradient stays in accumulator registers over the whole run and is added to gw once per workgroup with
+// coalesced float atomics (a row of D is contiguous in gw).
+// =====================================================================================================================
+namespace {
+
+struct WgSmallArgs {
+  const float* x;
+  const float* go;
+  float* gw;
+  int B, H, W, Ho, Wo, pad, tiles_x, tiles_y, ntiles;
+};
+
+template <int COUT, int CIN, int K, int S>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_small_kernel(WgSmallArgs a) {
+  constexpr int TH = S == 2 ? 4 : 8, TW = 32, NPX = TH * TW;   // (stride 2: 4 rows keep two workgroups per CU)
+  constexpr int NN = CIN * K * K, NTL = (NN + 15) / 16, MTL = COUT / 16;
+  constexpr int RH = S * TH + K - S, RWC = S * TW + K - S, RP = RWC + 1, PLANE = RH * RP;
+  constexpr int GP = NPX + 4;                                  // grad_out pitch: 4 (mod 32) -> conflict-free A reads
+  constexpr int XCELLS = CIN * RH * RWC, NXL = (XCELLS + 255) / 256, XB = 8;      // region loads per thread, batch
+  constexpr int NG4 = COUT * NPX / 4 / 256;                                       // grad_out float4 per thread
+  __shared__ float gs[COUT * GP];
+  __shared__ float xs[CIN * PLANE + 1];                        // + one zero cell for the padding columns
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, g = lane >> 4, n = lane & 15;
+  const int HWo = a.Ho * a.Wo, HWi = a.H * a.W;
+  if (tid == 0) xs[CIN * PLANE] = 0.f;
+
+  // this lane's column of every fragment: LDS offset of (ci, ky, kx); padding columns read the zero cell
+  int noff[NTL], nmul[NTL];
+#pragma unroll
+  for (int j = 0; j < NTL; ++j) {
+    const int idx = 16 * j + n;
+    const int ci = idx / (K * K), r = idx - ci * (K * K), ky = r / K, kx = r - ky * K;
+    noff[j] = idx < NN ? ci * PLANE + ky * RP + kx : CIN * PLANE;
+    nmul[j] = idx < NN ? S : 0;
+  }
+  f32x4 acc[NTL][MTL];
+#pragma unroll
+  for (int j = 0; j < NTL; ++j)
+#pragma unroll
+    for (int m = 0; m < MTL; ++m) acc[j][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int per_img = a.tiles_x * a.tiles_y;
+  for (int t = blockIdx.x; t < a.ntiles; t += gridDim.x) {
+    const int b = t / per_img, tt = t - b * per_img;
+    const int oy0 = (tt / a.tiles_x) * TH, ox0 = (tt % a.tiles_x) * TW;
+    const int iy0 = S * oy0 - a.pad, ix0 = S * ox0 - a.pad;
+    const __amdgpu_buffer_rsrc_t rs_g = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.go + (long long)b * COUT * HWo), 0, (int)((unsigned)COUT * (unsigned)HWo * 4u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.x + (long long)b * CIN * HWi), 0, (int)((unsigned)CIN * (unsigned)HWi * 4u), 0x00020000);
+    __syncthreads();                                          // the previous tile's reads are done
+    {                                                         // grad_out tile: all loads first, then the stores
+      float gv[NG4][4];
+      const bool vec = (a.Wo & 3) == 0;                       // rows of 32: float4 when the row pitch allows
+#pragma unroll
+      for (int i = 0; i < NG4; ++i) {
+        const int u = tid + 256 * i, co = u / (NPX / 4), q = u - co * (NPX / 4), oy = oy0 + q / 8, ox = ox0 + 4 * (q % 8);
+        const unsigned base = ((unsigned)co * (unsigned)HWo + (unsigned)(oy * a.Wo + ox)) * 4u;
+        if (vec) {
+          const bool ok = oy < a.Ho && ox < a.Wo;
+          const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_g, ok ? base : 0xFFFFFFF0u, 0, 0));
+          gv[i][0] = v.x; gv[i][1] = v.y; gv[i][2] = v.z; gv[i][3] = v.w;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const bool ok = oy < a.Ho && ox + e < a.Wo;
+            gv[i][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_g, ok ? base + 4u * e : 0xFFFFFFF0u, 0, 0));
+          }
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < NG4; ++i) {
+        const int u = tid + 256 * i, co = u / (NPX / 4), q = u - co * (NPX / 4);
+        *reinterpret_cast<f32x4*>(&gs[co * GP + 4 * q]) = f32x4{gv[i][0], gv[i][1], gv[i][2], gv[i][3]};
+      }
+    }
+#pragma unroll 1
+    for (int i0 = 0; i0 < NXL; i0 += XB) {                    // input halo region, zero outside the image
+      float xv[XB];
+#pragma unroll
+      for (int i = 0; i < XB; ++i) {
+        const int e = tid + 256 * (i0 + i);
+        const int ci = e / (RH * RWC), r = e - ci * (RH * RWC), ry = r / RWC, rx = r - ry * RWC;
+        const int iy = iy0 + ry, ix = ix0 + rx;
+        const bool ok = i0 + i < NXL && e < XCELLS && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+        const unsigned o = ok ? ((unsigned)ci * (unsigned)HWi + (unsigned)(iy * a.W + ix)) * 4u : 0xFFFFFFF0u;
+        xv[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_x, o, 0, 0));
+      }
+#pragma unroll
+      for (int i = 0; i < XB; ++i) {
+        const int e = tid + 256 * (i0 + i);
+        if (i0 + i < NXL && e < XCELLS) {
+          const int ci = e / (RH * RWC), r = e - ci * (RH * RWC), ry = r / RWC, rx = r - ry * RWC;
+          xs[ci * PLANE + ry * RP + rx] = xv[i];
+        }
+      }
+    }
+    __syncthreads();
+
+    // wave w contracts the k-steps w, w + 4, ... (4 pixels each) against ALL column fragments
+#pragma unroll 2
+    for (int it = 0; it < NPX / 16; ++it) {
+      const int ks = wid + 4 * it;
+      const int p = 4 * ks + g, py = p / TW, px = p % TW;
+      const int poff = py * RP + px;
+      float av[MTL], bv[NTL];
+#pragma unroll
+      for (int m = 0; m < MTL; ++m) av[m] = gs[(16 * m + n) * GP + p];
+#pragma unroll
+      for (int j = 0; j < NTL; ++j) bv[j] = xs[noff[j] + nmul[j] * poff];
+#pragma unroll
+      for (int j = 0; j < NTL; ++j)
+#pragma unroll
+        for (int m = 0; m < MTL; ++m) acc[j][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m], bv[j], acc[j][m], 0, 0, 0);
+    }
+  }
+
+  // flush: D[co = 16 m + 4 g + r][column = 16 j + n]; gw[co][column] is contiguous in the column
+#pragma unroll
+  for (int j = 0; j < NTL; ++j) {
+    const int idx = 16 * j + n;
+    if (idx < NN) {
+#pragma unroll
+      for (int m = 0; m < MTL; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) atomicAdd(&a.gw[(16 * m + 4 * g + r) * NN + idx], acc[j][m][r]);
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int cp_conv_direct_wgrad_supported(int32_t Cin, int32_t Cout, int32_t k, int32_t stride, int32_t pad) {
+  return (k == 7 && Cin == 3 && Cout == 16 && stride == 1 && pad == 3) ||
+         (k == 3 && Cin == 16 && Cout == 32 && stride == 2 && pad == 1) ||
+         (k == 3 && Cin == 16 && Cout == 16 && stride == 1 && pad == 1);
+}
+
+// gw [Cout][Cin][k][k] is ACCUMULATED into (float atomics; zero it first).
+extern "C" int cp_conv_direct_wgrad(const float* x, const float* go, float* gw, int32_t B, int32_t Cin, int32_t H,
+                                    int32_t W, int32_t Cout, int32_t k, int32_t stride, int32_t pad, void* stream) {
+  CP_CHECK_ARG(x && go && gw && B > 0 && H > 0 && W > 0);
+  if (!cp_conv_direct_wgrad_supported(Cin, Cout, k, stride, pad)) return CP_EUNSUPPORTED;
+  WgSmallArgs a;
+  a.x = x; a.go = go; a.gw = gw; a.B = B; a.H = H; a.W = W; a.pad = pad;
+  a.Ho = (H + 2 * pad - k) / stride + 1;
+  a.Wo = (W + 2 * pad - k) / stride + 1;
+  if ((unsigned long long)Cin * H * W * 4ull >= 0x70000000ull || (unsigned long long)Cout * a.Ho * a.Wo * 4ull >= 0x70000000ull)
+    return CP_EUNSUPPORTED;
+  a.tiles_x = (a.Wo + 31) / 32;
+  const int th = stride == 2 ? 4 : 8;
+  a.tiles_y = (a.Ho + th - 1) / th;
+  a.ntiles = a.tiles_x * a.tiles_y * B;
+  const int grid = a.ntiles < 512 ? a.ntiles : 512;            // two workgroups per CU, each a grid-stride run
+  hipStream_t st = (hipStream_t)stream;
+  if (k == 7) hipLaunchKernelGGL((conv_wgrad_small_kernel<16, 3, 7, 1>), dim3(grid), dim3(256), 0, st, a);
+  else if (stride == 2) hipLaunchKernelGGL((conv_wgrad_small_kernel<32, 16, 3, 2>), dim3(grid), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((conv_wgrad_small_kernel<16, 16, 3, 1>), dim3(grid), dim3(256), 0, st, a);
+  return cp_launch_status();
+}

@@ -11,6 +11,7 @@ unchanged.  Differences, all deliberate:
     into the DCN epilogue) instead of three passes over the feature map.
 """
 import math
+import os
 
 import numpy as np
 import torch
@@ -74,8 +75,8 @@ def _conv_direct(x, conv, wb, relu):
 
 
 class _DirectConvFn(torch.autograd.Function):
-    """Training forward of a bias-free convolution through the direct kernel; the gradients are the
-    library's (torch.nn.grad), only for the inputs that need them."""
+    """Training forward of a bias-free convolution of the DLA base through the direct kernel; weight gradient
+    from cp_conv_direct_wgrad, level0's input gradient from the MFMA convolution, level1's from the library."""
 
     @staticmethod
     def forward(ctx, x, weight, stride, pad):
@@ -94,15 +95,31 @@ class _DirectConvFn(torch.autograd.Function):
         x, weight = ctx.saved_tensors
         stride, pad = ctx.cfg
         go = go.contiguous()
+        direct_w = os.environ.get("CP_CONV_DIRECT_WGRAD", "1") != "0"
+        gx = gw = None
         if weight.shape[2] == 3 and stride == 1 and pad == 1 and conv3x3.mfma_enabled():
-            # level0 (16 -> 16 at full resolution): both gradients through the split-bf16 MFMA kernels -- most of
-            # their 32 / 64-channel tiles multiply zeros, but the layer is bandwidth-bound and the library's
-            # NHWC round trip (transposes + implicit GEMM) costs 5x more
-            return conv3x3.grads(x, weight, go, ctx.needs_input_grad[0], ctx.needs_input_grad[1]) + (None, None)
-        gx = torch.nn.grad.conv2d_input(x.shape, weight, go, stride=stride, padding=pad) \
-            if ctx.needs_input_grad[0] else None
-        gw = torch.nn.grad.conv2d_weight(x, weight.shape, go, stride=stride, padding=pad) \
-            if ctx.needs_input_grad[1] else None
+            # level0 (16 -> 16 at full resolution): the input gradient through the split-bf16 MFMA kernel (most of
+            # its 32-channel tiles multiply zeros, but the layer is bandwidth-bound and the library's NHWC round
+            # trip costs 5x more); the weight gradient from the direct kernel below
+            gx, gw = conv3x3.grads(x, weight, go, ctx.needs_input_grad[0], ctx.needs_input_grad[1] and not direct_w)
+        elif ctx.needs_input_grad[0]:
+            gx = torch.nn.grad.conv2d_input(x.shape, weight, go, stride=stride, padding=pad)
+        if ctx.needs_input_grad[1] and gw is None:
+            L = _C.lib()
+            B, cin, H, W = x.shape
+            cout, k = weight.shape[0], weight.shape[2]
+            if direct_w and L.cp_conv_direct_wgrad_supported(cin, cout, k, stride, pad):
+                # pixel-contraction kernel on the exact f32 MFMA instead of the library's NHWC implicit GEMM behind
+                # two full-resolution layout transposes
+                gw = torch.zeros_like(weight)
+                rc = L.cp_conv_direct_wgrad(_C.ptr(x), _C.ptr(go), _C.ptr(gw), B, cin, H, W, cout, k, stride, pad,
+                                            _C.stream())
+                if rc == -2:
+                    gw = None
+                else:
+                    _C.check(rc, "cp_conv_direct_wgrad")
+            if gw is None:
+                gw = torch.nn.grad.conv2d_weight(x, weight.shape, go, stride=stride, padding=pad)
         return gx, gw, None, None
 
 

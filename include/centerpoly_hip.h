@@ -203,6 +203,14 @@ int cp_conv3x3_mfma_wgrad_supported(int32_t Cin, int32_t Cout, int32_t H, int32_
 int cp_conv3x3_mfma_wgrad(const float* x, const float* go, float* gw, int32_t B, int32_t Cin, int32_t H, int32_t W,
                           int32_t Cout, void* stream);
 
+/* Weight gradient of the same three full-resolution layers (cuDNN backward-filter in the reference), exact fp32 MFMA:
+ *   gw[co][ci][ky][kx] += sum_{b,y,x} go[b][co][y][x] * x[b][ci][y*stride - pad + ky][x*stride - pad + kx]
+ * gw [Cout][Cin][k][k] is ACCUMULATED into (float atomics: zero it first).  Shapes: (k 7, 3->16, stride 1, pad 3),
+ * (k 3, 16->16, stride 1, pad 1), (k 3, 16->32, stride 2, pad 1); cp_conv_direct_wgrad_supported tells. */
+int cp_conv_direct_wgrad_supported(int32_t Cin, int32_t Cout, int32_t k, int32_t stride, int32_t pad);
+int cp_conv_direct_wgrad(const float* x, const float* go, float* gw, int32_t B, int32_t Cin, int32_t H, int32_t W,
+                         int32_t Cout, int32_t k, int32_t stride, int32_t pad, void* stream);
+
 /* Output stage of a detection head at inference (the `fc` Sequential of DLASeg,
  * src/lib/models/networks/pose_dla_dcn.py:445-462: Conv2d 3x3 + bias -> ReLU -> Conv2d 1x1 + bias),
  * everything after the 3x3 convolution's matrix product, one pass:

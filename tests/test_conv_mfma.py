@@ -233,3 +233,26 @@ def test_training_trajectory_matches_exact_arithmetic():
     for a, b in zip(*runs):
         assert abs(a["hm_l"] - b["hm_l"]) <= 2e-2 * b["hm_l"], (a["hm_l"], b["hm_l"])
     assert runs[0][-1]["hm_l"] < 0.6 * runs[0][0]["hm_l"]    # and it does learn
+
+
+# (Cin, Cout, k, stride, pad): stem, level0, level1 of the DLA base; map sizes off the 8 x 32 (4 x 32) tile grid
+SMALL = [(3, 16, 7, 1, 3), (16, 16, 3, 1, 1), (16, 32, 3, 2, 1)]
+
+
+@pytest.mark.parametrize("cfg", SMALL, ids=["stem7x7", "level0", "level1s2"])
+@pytest.mark.parametrize("hw", [(40, 72), (17, 33), (64, 256)], ids=["40x72", "17x33", "64x256"])
+def test_direct_weight_gradient_of_the_base_layers(cfg, hw):
+    cin, cout, k, stride, pad = cfg
+    H, W = hw
+    L = _C.lib()
+    assert L.cp_conv_direct_wgrad_supported(cin, cout, k, stride, pad)
+    x = _t("dw/x%s%s" % (cfg, hw), (3, cin, H, W))
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    go = _t("dw/go%s%s" % (cfg, hw), (3, cout, Ho, Wo))
+    gw = torch.zeros((cout, cin, k, k), device=DEV)
+    _C.check(L.cp_conv_direct_wgrad(P(x), P(go), P(gw), 3, cin, H, W, cout, k, stride, pad, _C.stream()), "wgrad")
+    ref = torch.nn.grad.conv2d_weight(x.double(), (cout, cin, k, k), go.double(), stride=stride, padding=pad)
+    assert _rel(gw, ref) <= 2e-6                       # exact f32 products, f32 accumulation
+    _C.check(L.cp_conv_direct_wgrad(P(x), P(go), P(gw), 3, cin, H, W, cout, k, stride, pad, _C.stream()), "wgrad")
+    assert _rel(gw, 2.0 * ref) <= 2e-6                 # accumulates
+    assert not L.cp_conv_direct_wgrad_supported(16, 16, 3, 2, 1)

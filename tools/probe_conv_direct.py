@@ -48,3 +48,29 @@ for name, cout, k, stride in (("stem 7x7 3->16", 16, 7, 1), ("level0 3x3 16->16"
     td, tl = timeit(direct), timeit(library)
     print("%-22s direct %7.1f us (%5.1f TFLOP/s)   library conv + bias/ReLU pass %7.1f us" % (name, td, flops / td / 1e6, tl), flush=True)
     x, cin = out.clone(), cout
+
+
+def wgrad(cin, cout, k, stride, pad, B=4, H=512, W=1024):
+    x = torch.randn(B, cin, H, W, device="cuda")
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    go = torch.randn(B, cout, Ho, Wo, device="cuda")
+    gw = torch.zeros(cout, cin, k, k, device="cuda")
+    L = _C.lib()
+    call = lambda: L.cp_conv_direct_wgrad(_C.ptr(x), _C.ptr(go), _C.ptr(gw), B, cin, H, W, cout, k, stride, pad, _C.stream())
+    lib = lambda: torch.nn.grad.conv2d_weight(x, (cout, cin, k, k), go, stride=stride, padding=pad)
+    out = []
+    for fn in (call, lib):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            fn()
+        e1.record(); torch.cuda.synchronize()
+        out.append(e0.elapsed_time(e1) / 10)
+    print("wgrad %d->%d k%d s%d @%dx%d x%d: direct %.3f ms   library %.3f ms" % (cin, cout, k, stride, H, W, B, out[0], out[1]), flush=True)
+
+
+for cfg in [(3, 16, 7, 1, 3), (16, 16, 3, 1, 1), (16, 32, 3, 2, 1)]:
+    wgrad(*cfg)
