@@ -407,13 +407,14 @@ __device__ __forceinline__ void split4(const f32x4 v, u32x2& hi, u32x2& lo) {
   lo = u32x2{__builtin_bit_cast(unsigned, l0), __builtin_bit_cast(unsigned, l1)};
 }
 
-template <int MTW>
+// TAPS = 1: the 1x1 convolution's weight gradient -- the same tiles and staging, only the centre tap contracted.
+template <int MTW, int TAPS>
 __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_kernel(WgArgs a) {
   constexpr int CO = 32 * MTW;
   constexpr int G_PLANE = CO * WG_GP, X_PLANE = WG_CI * WG_XP;                 // elements per half
   constexpr int G_ITERS = CO * 32 / 512, X_UNITS = WG_CI * 60, X_ITERS = (X_UNITS + 511) / 512;
   constexpr int STAGE_BYTES = (2 * G_PLANE + 2 * X_PLANE) * 2;
-  constexpr int OP = WG_CI * 9 + 1, OUT_BYTES = 32 * OP * 4;
+  constexpr int OP = WG_CI * TAPS + 1, OUT_BYTES = 32 * OP * 4;
   constexpr int SMEM = STAGE_BYTES > OUT_BYTES ? STAGE_BYTES : OUT_BYTES;
   __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];
   unsigned short* Gs = reinterpret_cast<unsigned short*>(smem);                // [2][G_PLANE]
@@ -426,9 +427,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_kernel(WgArgs a) {
   const int k_begin = blockIdx.x * a.tiles_per_wg;
   const int k_end = min(a.ntiles, k_begin + a.tiles_per_wg);
 
-  f32x4 acc[9][MTW];
+  f32x4 acc[TAPS][MTW];
 #pragma unroll
-  for (int t = 0; t < 9; ++t)
+  for (int t = 0; t < TAPS; ++t)
 #pragma unroll
     for (int m = 0; m < MTW; ++m) acc[t][m] = f32x4{0.f, 0.f, 0.f, 0.f};
 
@@ -510,7 +511,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_kernel(WgArgs a) {
         al[m] = *reinterpret_cast<const bf16x8*>(&Gs[G_PLANE + e]);
       }
 #pragma unroll
-      for (int dy = 0; dy < 3; ++dy) {
+      for (int dy = (TAPS == 9 ? 0 : 1); dy < (TAPS == 9 ? 3 : 2); ++dy) {
         const int e = b_base + (r + dy) * WG_XR;
         u32x4 bh[3], bl[3];                                          // dx = 0 (x - 1), 1 (x), 2 (x + 1)
 #pragma unroll
@@ -527,15 +528,15 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_kernel(WgArgs a) {
           dst[2] = u32x4{s01, s12, s23, __builtin_amdgcn_alignbit(pR, q[3], 16)};
         }
 #pragma unroll
-        for (int dx = 0; dx < 3; ++dx) {
+        for (int dx = (TAPS == 9 ? 0 : 1); dx < (TAPS == 9 ? 3 : 2); ++dx) {
           const bf16x8 fh = __builtin_bit_cast(bf16x8, bh[dx]), fl = __builtin_bit_cast(bf16x8, bl[dx]);
 #pragma unroll
           for (int m = 0; m < MTW; ++m) {
-            f32x4 v = acc[dy * 3 + dx][m];
+            f32x4 v = acc[TAPS == 9 ? dy * 3 + dx : 0][m];
             v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[m], fh, v, 0, 0, 0);
             v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[m], fl, v, 0, 0, 0);
             v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[m], fh, v, 0, 0, 0);
-            acc[dy * 3 + dx][m] = v;
+            acc[TAPS == 9 ? dy * 3 + dx : 0][m] = v;
           }
         }
       }
@@ -545,7 +546,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_kernel(WgArgs a) {
 
   // ---- flush: 32 output channels per pass through LDS, then coalesced atomics ----
   float* O = reinterpret_cast<float*>(smem);
-  const int ciw = min(WG_CI, a.Cin - ci0) * 9;
+  const int ciw = min(WG_CI, a.Cin - ci0) * TAPS;
 #pragma unroll
   for (int pass = 0; pass < CO / 32; ++pass) {
     __syncthreads();
@@ -554,16 +555,16 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_kernel(WgArgs a) {
       const int row0 = (mtb + m) * 16 + 4 * g;                       // rows row0 .. row0 + 3 lie in one pass
       if (row0 / 32 == pass) {
 #pragma unroll
-        for (int t = 0; t < 9; ++t)
+        for (int t = 0; t < TAPS; ++t)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) O[(row0 % 32 + r) * OP + (nt * 16 + c) * 9 + t] = acc[t][m][r];
+          for (int r = 0; r < 4; ++r) O[(row0 % 32 + r) * OP + (nt * 16 + c) * TAPS + t] = acc[t][m][r];
       }
     }
     __syncthreads();
     for (int idx = tid; idx < 32 * ciw; idx += 512) {
       const int row = idx / ciw, col = idx - row * ciw;
       const int co = co0 + pass * 32 + row;
-      if (co < a.Cout) atomicAdd(&a.gw[((long long)co * a.Cin + ci0) * 9 + col], O[row * OP + col]);
+      if (co < a.Cout) atomicAdd(&a.gw[((long long)co * a.Cin + ci0) * TAPS + col], O[row * OP + col]);
     }
   }
 }
@@ -577,11 +578,12 @@ int cp_conv3x3_mfma_wgrad_supported(int32_t Cin, int32_t Cout, int32_t H, int32_
          (long long)Cout * H * W * 4 < 0x7FFFFFF0ll;
 }
 
-// gw [Cout][Cin][3][3] += the weight gradient (the caller zeroes or carries an accumulation).
-int cp_conv3x3_mfma_wgrad(const float* x, const float* go, float* gw, int32_t B, int32_t Cin, int32_t H, int32_t W,
-                          int32_t Cout, void* stream) {
+// gw [Cout][Cin][k][k] += the weight gradient, k*k = taps (9: 3x3 / pad 1; 1: 1x1); the caller zeroes gw or carries
+// an accumulation.
+int cp_conv_mfma_wgrad(const float* x, const float* go, float* gw, int32_t B, int32_t Cin, int32_t H, int32_t W,
+                       int32_t Cout, int32_t taps, void* stream) {
   hipStream_t st = (hipStream_t)stream;
-  CP_CHECK_ARG(x && go && gw && B >= 1);
+  CP_CHECK_ARG(x && go && gw && B >= 1 && (taps == 1 || taps == 9));
   if (!cp_conv3x3_mfma_wgrad_supported(Cin, Cout, H, W)) return CP_EUNSUPPORTED;
   WgArgs a;
   a.x = x;
@@ -602,11 +604,20 @@ int cp_conv3x3_mfma_wgrad(const float* x, const float* go, float* gw, int32_t B,
   if (nsplit > a.ntiles) nsplit = a.ntiles;
   a.tiles_per_wg = (a.ntiles + nsplit - 1) / nsplit;
   nsplit = (a.ntiles + a.tiles_per_wg - 1) / a.tiles_per_wg;
-  if (MTW == 2)
-    hipLaunchKernelGGL((conv3x3_wgrad_kernel<2>), dim3(nsplit, pairs), dim3(512), 0, st, a);
-  else
-    hipLaunchKernelGGL((conv3x3_wgrad_kernel<1>), dim3(nsplit, pairs), dim3(512), 0, st, a);
+  const dim3 grid(nsplit, pairs);
+  if (taps == 9) {
+    if (MTW == 2) hipLaunchKernelGGL((conv3x3_wgrad_kernel<2, 9>), grid, dim3(512), 0, st, a);
+    else hipLaunchKernelGGL((conv3x3_wgrad_kernel<1, 9>), grid, dim3(512), 0, st, a);
+  } else {
+    if (MTW == 2) hipLaunchKernelGGL((conv3x3_wgrad_kernel<2, 1>), grid, dim3(512), 0, st, a);
+    else hipLaunchKernelGGL((conv3x3_wgrad_kernel<1, 1>), grid, dim3(512), 0, st, a);
+  }
   return cp_launch_status();
+}
+
+int cp_conv3x3_mfma_wgrad(const float* x, const float* go, float* gw, int32_t B, int32_t Cin, int32_t H, int32_t W,
+                          int32_t Cout, void* stream) {
+  return cp_conv_mfma_wgrad(x, go, gw, B, Cin, H, W, Cout, 9, stream);
 }
 
 }  // extern "C"

@@ -37,27 +37,31 @@ def usable_shape(x, cout):
 
 
 def usable(conv, x):
-    """True when conv(x) (without bias) is a launch of the MFMA kernel."""
-    return (conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1)
+    """True when conv(x) (without bias) is a launch of the MFMA kernel: 3x3 / pad 1 or 1x1, stride 1."""
+    k = conv.kernel_size
+    return (k in ((3, 3), (1, 1)) and conv.stride == (1, 1) and conv.padding == (k[0] // 2, k[0] // 2)
             and conv.dilation == (1, 1) and conv.groups == 1 and conv.padding_mode == "zeros"
             and usable_shape(x, conv.out_channels))
 
 
 def _prepare(weight, cin, cout, transposed):
     L = _C.lib()
-    wp = torch.empty(L.cp_conv3x3_mfma_weight_bytes(cin, cout), dtype=torch.uint8, device=weight.device)
-    _C.check(L.cp_conv3x3_mfma_prepare(_C.ptr(weight), cin, cout, 1 if transposed else 0, _C.ptr(wp), _C.stream()),
-             "cp_conv3x3_mfma_prepare")
+    taps = weight.shape[2] * weight.shape[3]
+    wp = torch.empty(L.cp_conv_mfma_weight_bytes(cin, cout, taps), dtype=torch.uint8, device=weight.device)
+    _C.check(L.cp_conv_mfma_prepare(_C.ptr(weight), cin, cout, taps, 1 if transposed else 0, _C.ptr(wp), _C.stream()),
+             "cp_conv_mfma_prepare")
     return wp
 
 
-def _launch(x, wp, bias, residual, cout, relu):
+def _launch(x, wp, bias, residual, cout, relu, taps=9):
     B, cin, H, W = x.shape
     out = torch.empty((B, cout, H, W), dtype=torch.float32, device=x.device)
-    end = _C.kernel_timer.start(("conv3x3_fwd", cin, cout, H, W, B)) if _C.kernel_timer is not None else None
-    _C.check(_C.lib().cp_conv3x3_mfma_forward(_C.ptr(x), _C.ptr(wp), _C.ptr(bias), _C.ptr(residual), _C.ptr(out),
-                                              B, cin, H, W, cout, 1 if relu else 0, _C.stream()),
-             "cp_conv3x3_mfma_forward")
+    tag = "conv3x3_fwd" if taps == 9 else "conv1x1_fwd"
+    end = _C.kernel_timer.start((tag, cin, cout, H, W, B)) if _C.kernel_timer is not None else None
+    ptrs, chans = (_C.c_void_p * 1)(x.data_ptr()), (_C.c_int32 * 1)(cin)
+    _C.check(_C.lib().cp_conv_mfma_forward(ptrs, chans, 1, _C.ptr(wp), _C.ptr(bias), _C.ptr(residual), _C.ptr(out),
+                                           B, H, W, cout, taps, 1 if relu else 0, _C.stream()),
+             "cp_conv_mfma_forward")
     if end is not None:
         end.record()
     return out
@@ -120,7 +124,7 @@ class _Conv3x3Fn(torch.autograd.Function):
     def forward(ctx, x, weight):
         ctx.save_for_backward(x, weight)
         cout, cin = weight.shape[0], weight.shape[1]
-        return _launch(x, _prepare(weight, cin, cout, False), None, None, cout, False)
+        return _launch(x, _prepare(weight, cin, cout, False), None, None, cout, False, weight.shape[2] * weight.shape[3])
 
     @staticmethod
     def backward(ctx, go):
@@ -134,27 +138,30 @@ def mfma_enabled():
 
 
 def grads(x, weight, go, want_x=True, want_w=True, min_k=1):
-    """(grad_x, grad_weight) of a 3x3 / stride 1 / pad 1 convolution from grad_out: the MFMA kernels where they
-    take the shape (the input gradient contracts over Cout: below `min_k` output channels it goes to the library)."""
+    """(grad_x, grad_weight) of a stride-1 3x3 / pad 1 or 1x1 convolution from grad_out: the MFMA kernels where
+    they take the shape (the input gradient contracts over Cout: below `min_k` output channels it goes to the
+    library)."""
     L = _C.lib()
     cout, cin = weight.shape[0], weight.shape[1]
+    taps, pad = weight.shape[2] * weight.shape[3], weight.shape[2] // 2
     B, _, H, W = x.shape
     gx = gw = None
     if want_x:
         if cout >= min_k and L.cp_conv3x3_mfma_supported(cout, cin, H, W):
-            gx = _launch(go, _prepare(weight, cout, cin, True), None, None, cin, False)
+            gx = _launch(go, _prepare(weight, cout, cin, True), None, None, cin, False, taps)
         else:
-            gx = torch.nn.grad.conv2d_input(x.shape, weight, go, padding=1)
+            gx = torch.nn.grad.conv2d_input(x.shape, weight, go, padding=pad)
     if want_w:
         if _WGRAD and L.cp_conv3x3_mfma_wgrad_supported(cin, cout, H, W):
             gw = torch.zeros_like(weight)
-            end = _C.kernel_timer.start(("conv3x3_wgrad", cin, cout, H, W, B)) if _C.kernel_timer is not None else None
-            _C.check(L.cp_conv3x3_mfma_wgrad(_C.ptr(x), _C.ptr(go), _C.ptr(gw), B, cin, H, W, cout, _C.stream()),
-                     "cp_conv3x3_mfma_wgrad")
+            tag = "conv3x3_wgrad" if taps == 9 else "conv1x1_wgrad"
+            end = _C.kernel_timer.start((tag, cin, cout, H, W, B)) if _C.kernel_timer is not None else None
+            _C.check(L.cp_conv_mfma_wgrad(_C.ptr(x), _C.ptr(go), _C.ptr(gw), B, cin, H, W, cout, taps, _C.stream()),
+                     "cp_conv_mfma_wgrad")
             if end is not None:
                 end.record()
         else:
-            gw = torch.nn.grad.conv2d_weight(x, weight.shape, go, padding=1)
+            gw = torch.nn.grad.conv2d_weight(x, weight.shape, go, padding=pad)
     return gx, gw
 
 

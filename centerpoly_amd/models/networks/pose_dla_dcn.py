@@ -299,7 +299,7 @@ class Root(nn.Module):
                 if y is not None:
                     return y
             return _conv_folded(torch.cat(xs, 1), self.conv, self._folded, relu=True, residual=res)
-        return bn_act(self.bn, self.conv(torch.cat(xs, 1)), relu=True,
+        return bn_act(self.bn, conv_train(self.conv, torch.cat(xs, 1)), relu=True,
                       residual=xs[0] if self.residual else None)
 
 
@@ -355,7 +355,7 @@ class Tree(nn.Module):
         elif _use_folded(self):
             residual = _conv_folded(bottom, self.project[0], self._folded)
         else:                                  # conv1x1 + BatchNorm (no activation), fused BN in training
-            residual = bn_act(self.project[1], self.project[0](bottom), relu=False)
+            residual = bn_act(self.project[1], conv_train(self.project[0], bottom), relu=False)
         if self.level_root:
             children.append(bottom)
         x1 = self.tree1(x, residual)

@@ -202,6 +202,9 @@ int cp_conv_mfma_forward(const float* const* xs, const int32_t* cs, int32_t nsrc
 int cp_conv3x3_mfma_wgrad_supported(int32_t Cin, int32_t Cout, int32_t H, int32_t W);
 int cp_conv3x3_mfma_wgrad(const float* x, const float* go, float* gw, int32_t B, int32_t Cin, int32_t H, int32_t W,
                           int32_t Cout, void* stream);
+/* the same with taps = 9 (3x3 / pad 1) or 1 (1x1: gw [Cout][Cin][1][1]) */
+int cp_conv_mfma_wgrad(const float* x, const float* go, float* gw, int32_t B, int32_t Cin, int32_t H, int32_t W,
+                       int32_t Cout, int32_t taps, void* stream);
 
 /* Weight gradient of the same three full-resolution layers (cuDNN backward-filter in the reference), exact fp32 MFMA:
  *   gw[co][ci][ky][kx] += sum_{b,y,x} go[b][co][y][x] * x[b][ci][y*stride - pad + ky][x*stride - pad + kx]

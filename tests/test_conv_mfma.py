@@ -256,3 +256,26 @@ def test_direct_weight_gradient_of_the_base_layers(cfg, hw):
     _C.check(L.cp_conv_direct_wgrad(P(x), P(go), P(gw), 3, cin, H, W, cout, k, stride, pad, _C.stream()), "wgrad")
     assert _rel(gw, 2.0 * ref) <= 2e-6                 # accumulates
     assert not L.cp_conv_direct_wgrad_supported(16, 16, 3, 2, 1)
+
+
+@pytest.mark.parametrize("shape", [(2, 128, 64, 40, 72), (1, 256, 27, 17, 36), (3, 64, 256, 9, 28), (2, 96, 8, 24, 64)],
+                         ids=["128->64", "256->27", "64->256", "96->8"])
+def test_1x1_weight_gradient_and_autograd(shape):
+    """The 1x1 form: weight gradient through the C ABI, and forward / both gradients through the autograd wrapper."""
+    from centerpoly_amd.models.networks import conv3x3
+    B, ci, co, H, W = shape
+    L = _C.lib()
+    x, go = _t("p1x%s" % (shape,), (B, ci, H, W)), _t("p1go%s" % (shape,), (B, co, H, W))
+    gw = torch.zeros((co, ci, 1, 1), device=DEV)
+    _C.check(L.cp_conv_mfma_wgrad(P(x), P(go), P(gw), B, ci, H, W, co, 1, _C.stream()), "wgrad")
+    ref = torch.nn.grad.conv2d_weight(x.double(), (co, ci, 1, 1), go.double())
+    assert _rel(gw, ref) <= TOL
+    conv = torch.nn.Conv2d(ci, co, 1, bias=False).to(DEV)
+    xr = x.clone().requires_grad_(True)
+    if conv3x3.usable(conv, xr):
+        y = conv3x3.conv_raw(conv, xr)
+        gx, gwa = torch.autograd.grad(y, (xr, conv.weight), go)
+        xd, wd = x.double().requires_grad_(True), conv.weight.detach().double().requires_grad_(True)
+        yd = F.conv2d(xd, wd)
+        gxd, gwd = torch.autograd.grad(yd, (xd, wd), go.double())
+        assert _rel(y, yd.detach()) <= TOL and _rel(gx, gxd) <= TOL and _rel(gwa, gwd) <= TOL
