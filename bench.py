@@ -61,8 +61,9 @@ def parse(argv=None):
     p.add_argument("--width", type=int, default=2048)
     p.add_argument("--train_batch", type=int, default=4, help="images per GPU in training")
     p.add_argument("--train_steps", type=int, default=8, help="steps of the N=1 training point")
-    p.add_argument("--dcn_contraction", default="f32", choices=["f32", "bf16x3"],
-                   help="DCNv2 forward contraction at inference: exact fp32 MFMA or split-bf16 x3")
+    p.add_argument("--dcn_contraction", default="auto", choices=["auto", "f32", "bf16x3"],
+                   help="DCNv2 forward contraction at inference: exact fp32 MFMA, split-bf16 x3, or auto (split-bf16 "
+                        "for the layers with > 64 output channels)")
     p.add_argument("--graph", action="store_true",
                    help="time one HIP-graph replay per inference step instead of eager launches (measured: no "
                         "faster, the eager step is GPU-bound)")
@@ -139,7 +140,7 @@ def note(msg):
         print("[bench %s] %s" % (time.strftime("%H:%M:%S"), msg), file=sys.stderr, flush=True)
 
 
-def build_model(dev, train, dcn_contraction="f32", arch="dla_34", heads=None, offset_weight_scale=0.5):
+def build_model(dev, train, dcn_contraction="auto", arch="dla_34", heads=None, offset_weight_scale=0.5):
     import torch
     from centerpoly_amd import synth
     from centerpoly_amd.models.model import create_model

@@ -471,34 +471,59 @@ __global__ __launch_bounds__(256, WPS) void dcn_fwd_pipe_kernel(DcnFwdArgs a) {
 }
 
 // ---------------------------------------------------------- split-bf16 kernel ---
-// Same tiling and buffer-load gathers as dcn_fwd_kernel, but the contraction runs on the bf16
-// matrix cores as THREE products of bf16 halves with fp32 accumulation:
+// The interleaved kernel's tiling, pair gathers and pipelining with the contraction on the bf16 matrix cores as
+// THREE products of bf16 halves with fp32 accumulation:
 //     a*b ~= ah*bh + ah*bl + al*bh,   x = xh + xl,  xh = bf16(x), xl = bf16(x - xh)
-// (the dropped al*bl term is 2^-16 relative), i.e. an fp32 emulation, not a bf16 result.
-// v_mfma_f32_16x16x32_bf16 takes 16 cycles for 16x16x32 MACs vs 8 x 32 cycles for the same
-// tile on the fp32 16x16x4 form: 3 of them cost 48 vs 256 cycles.  Chunks are 8 input channels
-// = 72 k values, zero-padded to 96 (three 32-deep MFMA steps).  LDS tiles hold the hi and lo
-// halves row-major with 208-byte rows, which makes the 16-byte fragment reads conflict-free.
+// (the dropped al*bl term is 2^-16 relative), i.e. an fp32 emulation, not a bf16 result.  Why: the f32-input MFMA
+// executes on the SIMD's vector ALUs (SQ_VALU_MFMA_COEXEC_CYCLES = 0 in every profile of this path), so the layers
+// with >= 128 output channels -- 2304 MFMA cycles per 4-channel chunk against 1152 cycles of gathers -- are bound by
+// it; the bf16 cores run beside the VALU and leave the texture addresser as the only bound.
+// Chunks are 8 input channels = 72 k values (k = 9 channel + tap), zero-padded to 96 = three 32-deep MFMA steps.
+//   * weights: split and laid out in B-fragment order by dcn_fwd_wperm_kernel (once per weight tensor; cached by the
+//     caller at inference) and read straight from global memory -- no weight tile in LDS, no conversion here;
+//   * columns: wave w samples channels 2w, 2w + 1 of the chunk (lane = pixel), splits each value and stores the
+//     bf16 halves of its 18 k-values as 9 + 9 dwords into the pixel's row of a double-buffered [64][104] tile
+//     (208-byte rows: conflict-free 16-byte fragment reads);
+//   * per k-step: 2 x NT x 3 MFMAs of chunk i  ||  six values of chunk i + 1 built and stored  ||  their gathers
+//     re-issued for chunk i + 2 into the same registers; ONE barrier per chunk.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-__device__ __forceinline__ void split_bf16(float v, __bf16& hi, __bf16& lo) {
-  hi = (__bf16)v;
-  lo = (__bf16)(v - (float)hi);
+// wp[((ct * nchunk + chunk) * 3 + ks) * 2 + hl][lane][j] = half(hl) of W[co = 16 ct + (lane & 15)][ci = 8 chunk + k / 9][k % 9],
+// k = 32 ks + 8 (lane >> 4) + j  (zero for k >= 72, co >= Cout, ci >= Cin)
+__global__ __launch_bounds__(256) void dcn_fwd_wperm_kernel(const float* __restrict__ w, bf16x8* __restrict__ wp, int Cout,
+                                                            int Cin, int nchunk, int total) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= total) return;
+  const int lane = e & 63;
+  int r = e >> 6;
+  const int hl = r & 1;
+  r >>= 1;
+  const int ks = r % 3;
+  r /= 3;
+  const int chunk = r % nchunk, ct = r / nchunk;
+  const int co = ct * 16 + (lane & 15);
+  bf16x8 o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int k = 32 * ks + 8 * (lane >> 4) + j;
+    const int ci = chunk * 8 + k / TAPS, t = k % TAPS;
+    const float v = (k < 72 && co < Cout && ci < Cin) ? w[((long long)co * Cin + ci) * TAPS + t] : 0.f;
+    const __bf16 h = (__bf16)v;
+    o[j] = hl ? (__bf16)(v - (float)h) : h;
+  }
+  wp[e] = o;
 }
 
 template <int BN, int WPS>
-__global__ __launch_bounds__(256, WPS) void dcn_fwd_bf16x3_kernel(DcnFwdArgs a) {
+__global__ __launch_bounds__(256, WPS) void dcn_fwd_pipe_bf16_kernel(DcnFwdArgs a, const bf16x8* __restrict__ wp) {
   constexpr int KC = 8;
   constexpr int KK = KC * TAPS;          // 72
   constexpr int KP = 96;                 // padded k extent (3 MFMA steps of 32)
   constexpr int LDA = KP + 8;            // 104 bf16 = 208 B rows
   constexpr int NT = BN / 32;
-  constexpr int CPW = KC / 4;            // 2 channels sampled per wave per chunk
+  constexpr int HALF = BM * LDA, BUF = 2 * HALF;      // bf16 elements: one half, one buffer (hi | lo)
   extern __shared__ float lds[];
-  __bf16* colH = (__bf16*)lds;           // [BM][LDA]
-  __bf16* colL = colH + BM * LDA;
-  __bf16* wH = colL + BM * LDA;          // [BN][LDA]
-  __bf16* wL = wH + BN * LDA;
+  __bf16* col = (__bf16*)lds;            // [2 buffers][hi | lo][BM][LDA]
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int b = blockIdx.z % a.B;
@@ -508,45 +533,8 @@ __global__ __launch_bounds__(256, WPS) void dcn_fwd_bf16x3_kernel(DcnFwdArgs a) 
   const bool p_ok = p < HWo;
 
   float cw[TAPS][4];
-  unsigned coff[TAPS][4];
-  {
-    const int ho = p_ok ? p / a.Wo : 0;
-    const int wo = p_ok ? p - ho * a.Wo : 0;
-    const float* off = a.offset + (long long)b * a.offset_bstride;
-    const float* msk = a.mask + (long long)b * a.mask_bstride;
-    float oy[TAPS], ox[TAPS], mk[TAPS];
-#pragma unroll
-    for (int t = 0; t < TAPS; ++t) {
-      oy[t] = p_ok ? off[(long long)(2 * t) * HWo + p] : 0.f;
-      ox[t] = p_ok ? off[(long long)(2 * t + 1) * HWo + p] : 0.f;
-      mk[t] = p_ok ? msk[(long long)t * HWo + p] : 0.f;
-    }
-#pragma unroll
-    for (int t = 0; t < TAPS; ++t) {
-      const int ky = t / 3, kx = t - ky * 3;
-      float m = mk[t];
-      if (a.mask_is_logit) m = 1.f / (1.f + __expf(-m));
-      const float py = (float)(ho * a.stride - a.pad + ky * a.dil) + oy[t];
-      const float px = (float)(wo * a.stride - a.pad + kx * a.dil) + ox[t];
-      const bool inside = p_ok && py > -1.f && px > -1.f && py < (float)a.H && px < (float)a.W;
-      const float fy = floorf(py), fx = floorf(px);
-      const int y0 = (int)fy, x0 = (int)fx;
-      const float ly = py - fy, lx = px - fx;
-      const float hy = 1.f - ly, hx = 1.f - lx;
-      const bool y0ok = y0 >= 0, y1ok = y0 + 1 <= a.H - 1;
-      const bool x0ok = x0 >= 0, x1ok = x0 + 1 <= a.W - 1;
-      const int y0c = min(max(y0, 0), a.H - 1), y1c = min(max(y0 + 1, 0), a.H - 1);
-      const int x0c = min(max(x0, 0), a.W - 1), x1c = min(max(x0 + 1, 0), a.W - 1);
-      cw[t][0] = (inside && y0ok && x0ok) ? hy * hx * m : 0.f;
-      cw[t][1] = (inside && y0ok && x1ok) ? hy * lx * m : 0.f;
-      cw[t][2] = (inside && y1ok && x0ok) ? ly * hx * m : 0.f;
-      cw[t][3] = (inside && y1ok && x1ok) ? ly * lx * m : 0.f;
-      coff[t][0] = inside ? 4u * (unsigned)(y0c * a.W + x0c) : 0u;
-      coff[t][1] = inside ? 4u * (unsigned)(y0c * a.W + x1c) : 0u;
-      coff[t][2] = inside ? 4u * (unsigned)(y1c * a.W + x0c) : 0u;
-      coff[t][3] = inside ? 4u * (unsigned)(y1c * a.W + x1c) : 0u;
-    }
-  }
+  unsigned coff[TAPS][2];
+  pair_recipe(a, b, p, p_ok, cw, coff);
 
   f32x4 acc[2][NT];
 #pragma unroll
@@ -555,114 +543,108 @@ __global__ __launch_bounds__(256, WPS) void dcn_fwd_bf16x3_kernel(DcnFwdArgs a) 
     for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int wm = wid >> 1, wn = wid & 1;
-  const int Ktot = a.Cin * TAPS;
   const float* xb = a.x + (long long)b * a.Cin * HW;
   const int ksl = (a.splitk > 1) ? (int)(blockIdx.z / a.B) : 0;
   const int c_begin = ksl * a.c_per_split;
   const int c_end = min(a.Cin, c_begin + a.c_per_split);
+  const int nchunk = (a.Cin + KC - 1) / KC;
 
   const unsigned plane_bytes = (unsigned)HW * 4u;
   const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(xb), 0, (int)((unsigned)a.Cin * plane_bytes), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(a.weight), 0, (int)((unsigned)a.Cout * (unsigned)Ktot * 4u), 0x00020000);
-  // weight staging: thread -> row (tid>>2) [+64 per pass], quarter (tid&3) = 18 consecutive k
-  constexpr int QW = KK / 4;             // 18
-  constexpr int WPASS = BN / 64;
-  const int wrow = tid >> 2, wq = tid & 3;
-  unsigned wbase[WPASS];
-#pragma unroll
-  for (int ps = 0; ps < WPASS; ++ps) {
-    const int co = n0 + ps * 64 + wrow;
-    wbase[ps] = co < a.Cout ? ((unsigned)co * (unsigned)Ktot + (unsigned)(wq * QW)) * 4u : 0xffffffffu;
-  }
   const int swid = __builtin_amdgcn_readfirstlane(wid);
 
-  // zero the k padding [72, 96) of all four tiles once
-  for (int e = tid; e < (BM + BN) * (KP - KK); e += 256) {
+  // zero the k padding [72, 96) of both buffers' halves once
+  for (int e = tid; e < 4 * BM * (KP - KK); e += 256) {
     const int row = e / (KP - KK), kk = KK + (e - row * (KP - KK));
-    if (row < BM) { colH[row * LDA + kk] = (__bf16)0.f; colL[row * LDA + kk] = (__bf16)0.f; }
-    else { wH[(row - BM) * LDA + kk] = (__bf16)0.f; wL[(row - BM) * LDA + kk] = (__bf16)0.f; }
+    col[row * LDA + kk] = (__bf16)0.f;                    // rows run over [buffer][half][pixel]
   }
 
-  float g[CPW][TAPS][4];
-  float wreg[WPASS][QW];
-  auto issue_loads = [&](int c0) {
-    const unsigned wk = (unsigned)(c0 * TAPS) * 4u;   // in voffset: soffset is not range-checked
+  float g[2][TAPS][4];                                    // gathers of this wave's two channels
+  auto load_unit = [&](int c0, int u) __attribute__((always_inline)) {   // unit u = cc * 9 + t
+    const int cc = u / TAPS, t = u % TAPS;
+    // soffset is not range-checked: clamp the channel plane (foreign samples are zeroed when built)
+    const unsigned xsoff = (unsigned)min(c0 + 2 * swid + cc, a.Cin - 1) * plane_bytes;
 #pragma unroll
-    for (int ps = 0; ps < WPASS; ++ps)
-#pragma unroll
-      for (int i = 0; i < QW; ++i)
-        wreg[ps][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                                                     rs_w, wbase[ps] == 0xffffffffu ? 0xffffffffu : wbase[ps] + wk + 4u * i, 0, 0));
-#pragma unroll
-    for (int cc = 0; cc < CPW; ++cc) {
-      const unsigned xsoff = (unsigned)min(c0 + swid * CPW + cc, a.Cin - 1) * plane_bytes;
-#pragma unroll
-      for (int t = 0; t < TAPS; ++t)
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-          g[cc][t][k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_x, coff[t][k], xsoff, 0));
+    for (int k = 0; k < 2; ++k) {
+      const f32x2 v = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_x, coff[t][k], xsoff, 0));
+      g[cc][t][2 * k] = v.x;
+      g[cc][t][2 * k + 1] = v.y;
     }
   };
-  auto write_lds = [&](int c0) {
+  auto value = [&](int c0, int u) __attribute__((always_inline)) -> float {
+    const int cc = u / TAPS, t = u % TAPS;
+    const float v = cw[t][0] * g[cc][t][0] + cw[t][1] * g[cc][t][1] + cw[t][2] * g[cc][t][2] + cw[t][3] * g[cc][t][3];
+    return (c0 + 2 * swid + cc < c_end) ? v : 0.f;        // split-K / ragged Cin: foreign channels contribute 0
+  };
+  // dwords 3 s .. 3 s + 2 of this wave's 18 k-values (k = 18 wid + 2 d, + 1) of chunk c0 -> buffer `buf`,
+  // then the same six units' gathers for chunk c0 + KC
+  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+  auto build_third = [&](__bf16* buf, int c0, int s_, bool reissue) __attribute__((always_inline)) {
+    unsigned* rowH = reinterpret_cast<unsigned*>(buf + lane * LDA + 18 * swid);
+    unsigned* rowL = reinterpret_cast<unsigned*>(buf + HALF + lane * LDA + 18 * swid);
 #pragma unroll
-    for (int cc = 0; cc < CPW; ++cc) {
-      const int cl = swid * CPW + cc;
-      const bool c_ok = c0 + cl < c_end;
-#pragma unroll
-      for (int t = 0; t < TAPS; ++t) {
-        float v = cw[t][0] * g[cc][t][0] + cw[t][1] * g[cc][t][1] + cw[t][2] * g[cc][t][2] +
-                  cw[t][3] * g[cc][t][3];
-        v = c_ok ? v : 0.f;
-        __bf16 h, l;
-        split_bf16(v, h, l);
-        colH[lane * LDA + cl * TAPS + t] = h;
-        colL[lane * LDA + cl * TAPS + t] = l;
-      }
+    for (int d = 3 * s_; d < 3 * s_ + 3; ++d) {
+      const float v0 = value(c0, 2 * d), v1 = value(c0, 2 * d + 1);
+      bf16x2 h, l;
+      h[0] = (__bf16)v0;
+      h[1] = (__bf16)v1;
+      l[0] = (__bf16)(v0 - (float)h[0]);
+      l[1] = (__bf16)(v1 - (float)h[1]);
+      rowH[d] = __builtin_bit_cast(unsigned, h);
+      rowL[d] = __builtin_bit_cast(unsigned, l);
     }
+    if (reissue) {
 #pragma unroll
-    for (int ps = 0; ps < WPASS; ++ps)
-#pragma unroll
-      for (int i = 0; i < QW; ++i) {
-        const bool k_ok = c0 * TAPS + wq * QW + i < c_end * TAPS;
-        __bf16 h, l;
-        split_bf16(k_ok ? wreg[ps][i] : 0.f, h, l);
-        wH[(ps * 64 + wrow) * LDA + wq * QW + i] = h;
-        wL[(ps * 64 + wrow) * LDA + wq * QW + i] = l;
-      }
+      for (int u = 6 * s_; u < 6 * s_ + 6; ++u) load_unit(c0 + KC, u);
+    }
   };
 
-  if (c_begin < c_end) issue_loads(c_begin);
-  for (int c0 = c_begin; c0 < c_end; c0 += KC) {
-    __syncthreads();                     // previous chunk's fragment reads are done
-    write_lds(c0);
-    __syncthreads();
-    if (c0 + KC < c_end) issue_loads(c0 + KC);
-    const int arow = (wm * 32 + (lane & 15)) * LDA + 8 * (lane >> 4);
-    const int brow = (wn * (BN / 2) + (lane & 15)) * LDA + 8 * (lane >> 4);
+  // prologue: chunk 0 -> buffer 0, chunk 1's gathers in flight
 #pragma unroll
-    for (int ks = 0; ks < KP / 32; ++ks) {
-      bf16x8 ah[2], al[2], bh[NT], bl[NT];
+  for (int u = 0; u < 2 * TAPS; ++u) load_unit(c_begin, u);
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        ah[i] = *reinterpret_cast<const bf16x8*>(colH + arow + i * 16 * LDA + ks * 32);
-        al[i] = *reinterpret_cast<const bf16x8*>(colL + arow + i * 16 * LDA + ks * 32);
-      }
+  for (int s_ = 0; s_ < 3; ++s_) build_third(col, c_begin, s_, true);
+  __syncthreads();
+
+  const int arow = (wm * 32 + (lane & 15)) * LDA + 8 * (lane >> 4);
+  const bf16x8* wq = wp + lane;
+  const int ct0 = (n0 + wn * (BN / 2)) / 16;
+  int par = 0;
+  for (int c0 = c_begin; c0 < c_end; c0 += KC, par ^= 1) {
+    const __bf16* cur = col + par * BUF;
+    __bf16* nxt = col + (par ^ 1) * BUF;
+    const int chunk = c0 / KC;
+#pragma unroll
+    for (int ks = 0; ks < 3; ++ks) {                       // k-step ks of chunk c0  ||  a third of chunk c0 + KC
+      bf16x8 bh[NT], bl[NT], ah[2], al[2];
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
-        bh[j] = *reinterpret_cast<const bf16x8*>(wH + brow + j * 16 * LDA + ks * 32);
-        bl[j] = *reinterpret_cast<const bf16x8*>(wL + brow + j * 16 * LDA + ks * 32);
+        const bf16x8* q = wq + ((((long long)(ct0 + j) * nchunk + chunk) * 3 + ks) * 2) * 64;
+        bh[j] = q[0];
+        bl[j] = q[64];
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        ah[i] = *reinterpret_cast<const bf16x8*>(cur + arow + i * 16 * LDA + ks * 32);
+        al[i] = *reinterpret_cast<const bf16x8*>(cur + HALF + arow + i * 16 * LDA + ks * 32);
       }
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < NT; ++j) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-        }
+        for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+      build_third(nxt, c0 + KC, ks, true);
+      __builtin_amdgcn_sched_barrier(0);                   // keep the re-issued gathers where they are
     }
+    __syncthreads();                                       // nxt complete, cur free
   }
 
   const bool raw = a.splitk > 1;
@@ -780,14 +762,15 @@ int launch_pipe(const DcnFwdArgs& a, hipStream_t st) {
   return cp_launch_status();
 }
 
+size_t wperm_bytes(int Cin, int Cout) {                    // 16-row tiles padded to whole groups of 8 (BN = 128)
+  return (size_t)((Cout + 127) / 128 * 8) * ((Cin + 7) / 8) * 3 * 2 * 64 * 16;
+}
+
 template <int BN, int WPS>
-int launch_bf16x3(const DcnFwdArgs& a, hipStream_t st) {
-  const size_t lds = (size_t)2 * (BM + BN) * 104 * 2;      // hi + lo halves, 104 bf16 per row
-  if (lds > 64 * 1024)
-    (void)hipFuncSetAttribute((const void*)dcn_fwd_bf16x3_kernel<BN, WPS>,
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+int launch_bf16x3(const DcnFwdArgs& a, const void* wp, hipStream_t st) {
+  const size_t lds = (size_t)2 * 2 * BM * 104 * 2;         // two buffers x (hi | lo) x 64 rows of 104 bf16
   dim3 grid((a.Ho * a.Wo + BM - 1) / BM, (a.Cout + BN - 1) / BN, a.B * a.splitk);
-  hipLaunchKernelGGL((dcn_fwd_bf16x3_kernel<BN, WPS>), grid, dim3(256), lds, st, a);
+  hipLaunchKernelGGL((dcn_fwd_pipe_bf16_kernel<BN, WPS>), grid, dim3(256), lds, st, a, (const bf16x8*)wp);
   if (a.splitk > 1) {
     const long long n_per_b = (long long)a.Cout * a.Ho * a.Wo;
     long long nb = ((long long)a.B * n_per_b + 255) / 256;
@@ -809,8 +792,9 @@ extern "C" size_t cp_dcn_v2_forward_workspace_bytes(const cp_dcn_shape* s) {
   const int Wo = out_extent(s->W, s->pad, s->dil, s->stride);
   if (Ho <= 0 || Wo <= 0) return 0;
   const Plan p = make_plan(s->B, s->Cin, s->Cout, Ho * Wo);
-  if (p.splitk <= 1) return 0;
-  return (size_t)p.splitk * s->B * s->Cout * Ho * Wo * sizeof(float);
+  // [permuted weights of the split-bf16 contraction | K-split partial sums]
+  const size_t part = p.splitk <= 1 ? 0 : (size_t)p.splitk * s->B * s->Cout * Ho * Wo * sizeof(float);
+  return wperm_bytes(s->Cin, s->Cout) + part;
 }
 
 extern "C" int cp_dcn_v2_forward(const cp_dcn_shape* s, const float* x, const float* offset,
@@ -831,12 +815,14 @@ extern "C" int cp_dcn_v2_forward(const cp_dcn_shape* s, const float* x, const fl
   if (s->W < 2) return CP_EUNSUPPORTED;          // the x-pair gathers need two columns
   const Plan p = make_plan(s->B, s->Cin, s->Cout, Ho * Wo);
   if ((long long)s->B * p.splitk > 65535) return CP_EUNSUPPORTED;
-  if (p.splitk > 1) {
+  const size_t wpb = wperm_bytes(s->Cin, s->Cout);
+  const bool bf = contraction == CP_DCN_BF16X3 || contraction == CP_DCN_BF16X3_PREPARED;
+  if (p.splitk > 1 || bf) {
     if (!workspace || workspace_bytes < cp_dcn_v2_forward_workspace_bytes(s)) return CP_EWORKSPACE;
   }
   DcnFwdArgs a;
   a.x = x; a.offset = offset; a.mask = mask; a.weight = weight; a.bias = bias;
-  a.ep_scale = ep_scale; a.ep_shift = ep_shift; a.out = out; a.partial = (float*)workspace;
+  a.ep_scale = ep_scale; a.ep_shift = ep_shift; a.out = out; a.partial = (float*)((char*)workspace + (workspace ? wpb : 0));
   a.offset_bstride = offset_bstride; a.mask_bstride = mask_bstride;
   a.B = s->B; a.Cin = s->Cin; a.H = s->H; a.W = s->W; a.Cout = s->Cout; a.Ho = Ho; a.Wo = Wo;
   a.stride = s->stride; a.pad = s->pad; a.dil = s->dil;
@@ -849,11 +835,17 @@ extern "C" int cp_dcn_v2_forward(const cp_dcn_shape* s, const float* x, const fl
   }
 #endif
   hipStream_t st = (hipStream_t)stream;
-  CP_CHECK_ARG(contraction == CP_DCN_F32 || contraction == CP_DCN_BF16X3);
+  CP_CHECK_ARG(contraction == CP_DCN_F32 || bf);
   if ((unsigned long long)s->Cout * s->Cin * 9ull * 4ull >= 0xE0000000ull) return CP_EUNSUPPORTED;
-  if (contraction == CP_DCN_BF16X3 && p.bn <= 128 && (p.c_per_split % 8) == 0) {
-    if (p.bn == 64) return launch_bf16x3<64, 2>(a, st);
-    return launch_bf16x3<128, 1>(a, st);
+  if (bf && p.bn <= 128 && (p.c_per_split % 8) == 0) {
+    if (contraction == CP_DCN_BF16X3) {                     // (PREPARED: the workspace already holds them)
+      const int nchunk = (s->Cin + 7) / 8;
+      const int total = (int)(wpb / 16);
+      hipLaunchKernelGGL(dcn_fwd_wperm_kernel, dim3((total + 255) / 256), dim3(256), 0, st, weight, (bf16x8*)workspace,
+                         s->Cout, s->Cin, nchunk, total);
+    }
+    if (p.bn == 64) return launch_bf16x3<64, 2>(a, workspace, st);
+    return launch_bf16x3<128, 2>(a, workspace, st);
   }
   // A/B switch for timing runs (phase-separated kernel); read once per process, never on the call path
   static const bool phased = getenv("CP_DCN_PHASED") != nullptr;

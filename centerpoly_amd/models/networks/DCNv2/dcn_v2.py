@@ -9,6 +9,7 @@ raw 27-channel tensor (offsets + mask logits, sigmoid applied in-kernel), sample
 modulates and contracts on the matrix cores.  No chunk/cat/sigmoid/im2col tensors.
 """
 import math
+import os
 
 import torch
 import torch.nn.functional as F
@@ -28,9 +29,12 @@ def _shape(x, weight, stride, pad, dil, dg):
 
 
 def dcn_v2_forward_raw(x, om, weight, bias, stride=1, pad=1, dil=1, dg=1, ep_scale=None,
-                       ep_shift=None, relu=False, contraction="f32"):
+                       ep_shift=None, relu=False, contraction="f32", owner=None):
     """Forward on the raw offset/mask tensor `om` [B, 3*kh*kw, Ho, Wo] (mask as logits).
-    Optional fused per-channel epilogue out = act(acc*ep_scale + ep_shift)."""
+    Optional fused per-channel epilogue out = act(acc*ep_scale + ep_shift).
+    `owner` (inference, contraction "bf16x3"): a module on which the workspace -- whose head holds the split,
+    permuted weights -- is kept for as long as `weight` is the same unmodified tensor and the shape the same, so
+    that the permutation prologue runs once instead of per call."""
     L = _C.lib()
     s = _shape(x, weight, stride, pad, dil, dg)
     K = s.kh * s.kw
@@ -39,12 +43,23 @@ def dcn_v2_forward_raw(x, om, weight, bias, stride=1, pad=1, dil=1, dg=1, ep_sca
     bs = 3 * K * Ho * Wo
     mask_ptr = _C.c_void_p(om.data_ptr() + 4 * 2 * K * Ho * Wo)
     nws = L.cp_dcn_v2_forward_workspace_bytes(s)
-    ws = _C.workspace(nws, x.device) if nws else None
+    mode = _C.DCN_CONTRACTION[contraction]
+    ws = None
+    if owner is not None and mode == 1:
+        key = (weight._version, tuple(x.shape), tuple(om.shape))
+        cache = owner.__dict__.get("_dcn_fwd_ws")
+        if cache is not None and cache[0] is weight and cache[1] == key:
+            ws, mode = cache[2], 2                       # CP_DCN_BF16X3_PREPARED
+        else:
+            ws = _C.workspace(nws, x.device)
+            owner.__dict__["_dcn_fwd_ws"] = (weight, key, ws)
+    elif nws:
+        ws = _C.workspace(nws, x.device)
     timer = _C.kernel_timer
     end = timer.start(("dcn_fwd", s.Cin, s.Cout, Ho, Wo, s.B)) if timer is not None else None
     rc = L.cp_dcn_v2_forward(s, _C.ptr(x), _C.ptr(om), bs, mask_ptr, bs, 1, _C.ptr(weight),
                              _C.ptr(bias), _C.ptr(ep_scale), _C.ptr(ep_shift), 1 if relu else 0,
-                             _C.DCN_CONTRACTION[contraction], _C.ptr(out), _C.ptr(ws), nws, _C.stream())
+                             mode, _C.ptr(out), _C.ptr(ws), nws, _C.stream())
     if end is not None:
         end.record()
     _C.check(rc, "cp_dcn_v2_forward")
@@ -61,7 +76,9 @@ class _DCNv2Function(torch.autograd.Function):
         ctx.cfg = (stride, pad, dil, dg)
         ctx.save_for_backward(x, om, weight)
         ctx.has_bias = bias is not None
-        return dcn_v2_forward_raw(x, om, weight, bias, stride, pad, dil, dg)
+        # (as prepare_inference's "auto": split-bf16 for the layers bound by the f32 matrix pipe)
+        wide = weight.shape[0] > 64 and os.environ.get("CP_DCN_FWD_F32", "0") != "1"
+        return dcn_v2_forward_raw(x, om, weight, bias, stride, pad, dil, dg, contraction="bf16x3" if wide else "f32")
 
     @staticmethod
     def backward(ctx, grad_out):
@@ -184,4 +201,4 @@ class DCN(nn.Module):
             om = cm(x)
         return dcn_v2_forward_raw(x.contiguous(), om.contiguous(), self.weight, None, self.stride,
                                   self.padding, self.dilation, self.deformable_groups, ep_scale,
-                                  ep_shift, relu, getattr(self, "contraction", "f32"))
+                                  ep_shift, relu, getattr(self, "contraction", "f32"), owner=self)

@@ -64,8 +64,12 @@ enum { CP_REP_CARTESIAN = 0, CP_REP_POLAR = 1, CP_REP_POLAR_FIXED = 2 };
 /* contraction arithmetic of cp_dcn_v2_forward */
 enum {
   CP_DCN_F32 = 0,    /* fp32 MFMA, exact fp32 fma chain                                        */
-  CP_DCN_BF16X3 = 1  /* split-bf16: a*b ~ ah*bh + ah*bl + al*bh on bf16 MFMA, fp32 accumulate;
-                        ~2^-16 relative error, 4x less matrix-core time (inference option)   */
+  CP_DCN_BF16X3 = 1, /* split-bf16: a*b ~ ah*bh + ah*bl + al*bh on bf16 MFMA, fp32 accumulate;
+                        ~2^-16 relative error.  The weights are split and permuted into the
+                        head of `workspace` by a prologue launch of the call                  */
+  CP_DCN_BF16X3_PREPARED = 2 /* the same, and `workspace` still holds the permuted weights of an
+                        earlier CP_DCN_BF16X3 call with the same weight tensor (inference:
+                        one workspace per layer, prologue paid once)                          */
 };
 
 /* regression flavour for cp_gather_l1_* */
@@ -98,7 +102,8 @@ const char* cp_build_arch(void);
  * with ep_scale/ep_shift NULL meaning scale 1 / shift = bias; relu != 0 clamps at 0.
  * When ep_scale/ep_shift are given, bias must already be folded into ep_shift.
  * Small-spatial layers split K over workgroups; their partial sums live in the
- * caller's workspace (cp_dcn_v2_forward_workspace_bytes, may be 0 / NULL).
+ * caller's workspace (cp_dcn_v2_forward_workspace_bytes), behind the permuted weights of the
+ * split-bf16 contraction; with CP_DCN_F32 and no K split the workspace may be NULL.
  */
 typedef struct cp_dcn_shape {
   int32_t B, Cin, H, W, Cout;
@@ -106,7 +111,7 @@ typedef struct cp_dcn_shape {
   int32_t deformable_groups; /* only 1 is implemented */
 } cp_dcn_shape;
 
-size_t cp_dcn_v2_forward_workspace_bytes(const cp_dcn_shape* s); /* 0 for most shapes */
+size_t cp_dcn_v2_forward_workspace_bytes(const cp_dcn_shape* s);
 int cp_dcn_v2_forward(const cp_dcn_shape* s, const float* x, const float* offset,
                       int64_t offset_bstride, const float* mask, int64_t mask_bstride,
                       int32_t mask_is_logit, const float* weight, const float* bias,
