@@ -44,7 +44,9 @@ def test_argument_validation_without_gpu():
                                None, 0, None) == -1
     # small-spatial, wide layers split K and need a workspace; big maps do not
     assert L.cp_dcn_v2_forward_workspace_bytes(_C.DcnShape(1, 512, 32, 64, 256, 3, 3, 1, 1, 1, 1)) > 0
-    assert L.cp_dcn_v2_forward_workspace_bytes(_C.DcnShape(1, 64, 256, 512, 64, 3, 3, 1, 1, 1, 1)) == 0
+    # no K split at this shape: only the permuted weights of the split-bf16 contraction
+    # (8 sixteen-row tiles x 8 chunks of 8 channels x 3 k-steps x hi/lo x 64 lanes x 16 B)
+    assert L.cp_dcn_v2_forward_workspace_bytes(_C.DcnShape(1, 64, 256, 512, 64, 3, 3, 1, 1, 1, 1)) == 8 * 8 * 3 * 2 * 64 * 16
 
 
 def test_ops_refuse_host_tensors():
