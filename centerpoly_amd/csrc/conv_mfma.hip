@@ -70,17 +70,19 @@ struct CvArgs {
   const float* bias;      // [Cout] or null
   const float* res;       // same shape as out, or null
   float* out;
-  int Cin, H, W, Cout, nchunk, ncot, tiles_x, relu;
+  int Cin, H, W, Ho, Wo, Cout, nchunk, ncot, tiles_x, relu;   // H, W: input; Ho, Wo: output
 };
 
 // KS > 1 (deep, small layers whose grid cannot fill the chip -- one wave per SIMD exposes every load latency): the
 // workgroup is KS groups of 4 waves, group q takes the channel chunks q, q + KS, ... of the SAME output tile through
 // its own staged tile, so the sequential chunk steps drop KS-fold; the partial accumulators meet in LDS in a fixed
 // order (deterministic) and group 0 runs the epilogue.
-template <int MT, int RW, int TAPS, int KS = 1>
+// S = 2: stride 2 (the first convolution of DLA levels 2-5): the staged tile is 2 TH + 1 rows x 65 columns, the B
+// fragments are read at twice the pixel stride (32-byte lane stride: two-way bank conflicts on those reads).
+template <int MT, int RW, int TAPS, int KS = 1, int S = 1>
 __global__ __launch_bounds__(256 * KS, KS > 1 ? 4 : 2) void conv_mfma_kernel(CvArgs a) {
-  constexpr int HALO = TAPS == 9 ? 1 : 0, LW = TW + 2 * HALO;
-  constexpr int TH = 4 * RW, LH = TH + 2 * HALO, NT = 2 * RW, PLANE = 4 * LH * LW;   // PLANE: fragments per half
+  constexpr int HALO = TAPS == 9 ? 1 : 0, LW = S * TW + (TAPS == 9 ? 3 : 1) - S;
+  constexpr int TH = 4 * RW, LH = S * TH + (TAPS == 9 ? 3 : 1) - S, NT = 2 * RW, PLANE = 4 * LH * LW;   // fragments per half
   constexpr int UNITS = PLANE, ITERS = (UNITS + 255) / 256, SB = ITERS <= 6 ? ITERS : 5;
   constexpr int RED = (KS - 1) * 256 * MT * NT;                                     // f32x4 slots of the reduction
   constexpr int XS_F = KS * 2 * PLANE;
@@ -91,7 +93,7 @@ __global__ __launch_bounds__(256 * KS, KS > 1 ? 4 : 2) void conv_mfma_kernel(CvA
   const int tid = threadIdx.x & 255, lane = tid & 63, wid = tid >> 6, g = lane >> 4, c = lane & 15;
   const int cot = blockIdx.x % a.ncot, tile = blockIdx.x / a.ncot;
   const int x0 = (tile % a.tiles_x) * TW, y0 = (tile / a.tiles_x) * TH, b = blockIdx.y;
-  const int HW = a.H * a.W;
+  const int HW = a.H * a.W, HWo = a.Ho * a.Wo;              // input / output plane sizes
 
   // staging units of this thread: (channel group, row, col) -> byte offset of channel 0 of the group, or OOB
   unsigned soff[ITERS];
@@ -99,7 +101,7 @@ __global__ __launch_bounds__(256 * KS, KS > 1 ? 4 : 2) void conv_mfma_kernel(CvA
   for (int i = 0; i < ITERS; ++i) {
     const int u = tid + i * 256;
     const int col = u % LW, r = (u / LW) % LH, cg = u / (LW * LH);
-    const int gy = y0 - HALO + r, gx = x0 - HALO + col;
+    const int gy = S * y0 - HALO + r, gx = S * x0 - HALO + col;
     const bool ok = u < UNITS && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
     soff[i] = ok ? ((unsigned)(cg * 8) * (unsigned)HW + (unsigned)(gy * a.W + gx)) * 4u : OOB;
   }
@@ -124,7 +126,7 @@ __global__ __launch_bounds__(256 * KS, KS > 1 ? 4 : 2) void conv_mfma_kernel(CvA
   }
 
   // B fragment base of this lane: channel group g, wave's first row, col c (tile origin is (-HALO, -HALO))
-  const int bbase = (g * LH + wid * RW) * LW + c;
+  const int bbase = (g * LH + S * wid * RW) * LW + S * c;
 
   int src = 0, src_c0 = 0;                                    // source tensor of the current chunk, its first channel
   for (int chunk = grp; chunk - grp < a.nchunk; chunk += KS) {
@@ -188,7 +190,7 @@ __global__ __launch_bounds__(256 * KS, KS > 1 ? 4 : 2) void conv_mfma_kernel(CvA
       bf16x8 bh[NT], bl[NT];
 #pragma unroll
       for (int n = 0; n < NT; ++n) {
-        const int idx = bbase + ((n >> 1) + dy) * LW + (n & 1) * 16 + dx;
+        const int idx = bbase + (S * (n >> 1) + dy) * LW + S * (n & 1) * 16 + dx;
         bh[n] = Xs[idx];
         bl[n] = Xs[PLANE + idx];
       }
@@ -229,8 +231,8 @@ __global__ __launch_bounds__(256 * KS, KS > 1 ? 4 : 2) void conv_mfma_kernel(CvA
   }
 
   // epilogue: D[row = 4 g + r (co)][col = c (pixel)]
-  float* ob = a.out + (long long)b * a.Cout * HW;
-  const float* rb = a.res ? a.res + (long long)b * a.Cout * HW : nullptr;
+  float* ob = a.out + (long long)b * a.Cout * HWo;
+  const float* rb = a.res ? a.res + (long long)b * a.Cout * HWo : nullptr;
 #pragma unroll
   for (int m = 0; m < MT; ++m) {
 #pragma unroll
@@ -241,8 +243,8 @@ __global__ __launch_bounds__(256 * KS, KS > 1 ? 4 : 2) void conv_mfma_kernel(CvA
 #pragma unroll
       for (int n = 0; n < NT; ++n) {
         const int y = y0 + wid * RW + (n >> 1), x = x0 + (n & 1) * 16 + c;
-        if (y < a.H && x < a.W) {
-          const long long o = (long long)co * HW + (long long)y * a.W + x;
+        if (y < a.Ho && x < a.Wo) {
+          const long long o = (long long)co * HWo + (long long)y * a.Wo + x;
           float v = acc[m][n][r] + bv;
           if (rb) v += rb[o];
           if (a.relu) v = fmaxf(v, 0.f);
@@ -293,11 +295,12 @@ int cp_conv3x3_mfma_prepare(const float* weight, int32_t Cin, int32_t Cout, int3
 // The input is the channel concatenation of `nsrc` (1..4) tensors xs[i] = [B][cs[i]][H][W] (what the reference
 // builds with torch.cat before a 1x1 `Root` convolution, pose_dla_dcn.py:148-166) -- read in place, never
 // materialised.  With several sources every cs[i] must be a multiple of 32.  taps = 9: 3x3 / pad 1; taps = 1: 1x1.
-int cp_conv_mfma_forward(const float* const* xs, const int32_t* cs, int32_t nsrc, const void* wperm, const float* bias,
-                         const float* residual, float* out, int32_t B, int32_t H, int32_t W, int32_t Cout,
-                         int32_t taps, int32_t relu, void* stream) {
+int cp_conv_mfma_forward_strided(const float* const* xs, const int32_t* cs, int32_t nsrc, const void* wperm,
+                                 const float* bias, const float* residual, float* out, int32_t B, int32_t H, int32_t W,
+                                 int32_t Cout, int32_t taps, int32_t stride, int32_t relu, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   CP_CHECK_ARG(xs && cs && wperm && out && B >= 1 && nsrc >= 1 && nsrc <= MAXSRC && (taps == 1 || taps == 9));
+  if (stride != 1 && !(stride == 2 && taps == 9)) return CP_EUNSUPPORTED;
   CvArgs a;
   int Cin = 0;
   for (int i = 0; i < MAXSRC; ++i) {
@@ -318,19 +321,25 @@ int cp_conv_mfma_forward(const float* const* xs, const int32_t* cs, int32_t nsrc
   a.H = H;
   a.W = W;
   a.Cout = Cout;
+  a.Ho = (H - 1) / stride + 1;                       // (pad = k / 2)
+  a.Wo = (W - 1) / stride + 1;
   a.nchunk = (Cin + KC - 1) / KC;
-  a.tiles_x = (W + TW - 1) / TW;
+  a.tiles_x = (a.Wo + TW - 1) / TW;
   a.relu = relu;
+  const int Ho = a.Ho;
   // Tile variant by how many workgroups it yields (the chip wants >= 2 per CU): 64 output channels x 8 rows is the
   // most efficient (fewest fragment bytes per MFMA); layers that cannot fill the CUs with it take 32 channels
   // x 8 rows, then 32 x 4 rows.  <= 32 output channels: 32 x 16 rows, then the same narrow forms.
-  auto wgs = [&](int mt, int th) { return (long long)a.tiles_x * ((H + th - 1) / th) * B * ((Cout + 16 * mt - 1) / (16 * mt)); };
+  auto wgs = [&](int mt, int th) { return (long long)a.tiles_x * ((Ho + th - 1) / th) * B * ((Cout + 16 * mt - 1) / (16 * mt)); };
   auto launch = [&](auto kernel, int mt, int th, int ks) {
     a.ncot = (Cout + 16 * mt - 1) / (16 * mt);
-    const int tiles = a.tiles_x * ((H + th - 1) / th);
+    const int tiles = a.tiles_x * ((Ho + th - 1) / th);
     hipLaunchKernelGGL(kernel, dim3(tiles * a.ncot, B), dim3(256 * ks), 0, st, a);
   };
-  if (taps == 9) {
+  if (stride == 2) {                                 // 4-row tiles only (the staged tile is 9 x 65 pixels)
+    if (Cout > 32 && wgs(4, 4) >= 448) launch(conv_mfma_kernel<4, 1, 9, 1, 2>, 4, 4, 1);
+    else launch(conv_mfma_kernel<2, 1, 9, 1, 2>, 2, 4, 1);
+  } else if (taps == 9) {
     if (Cout > 32 && wgs(4, 8) >= 448) launch(conv_mfma_kernel<4, 2, 9>, 4, 8, 1);
     else if (Cout <= 32 && wgs(2, 16) >= 448) launch(conv_mfma_kernel<2, 4, 9>, 2, 16, 1);
     else if (wgs(2, 8) >= 320) launch(conv_mfma_kernel<2, 2, 9>, 2, 8, 1);
@@ -345,6 +354,12 @@ int cp_conv_mfma_forward(const float* const* xs, const int32_t* cs, int32_t nsrc
     else launch(conv_mfma_kernel<2, 1, 1>, 2, 4, 1);
   }
   return cp_launch_status();
+}
+
+int cp_conv_mfma_forward(const float* const* xs, const int32_t* cs, int32_t nsrc, const void* wperm, const float* bias,
+                         const float* residual, float* out, int32_t B, int32_t H, int32_t W, int32_t Cout,
+                         int32_t taps, int32_t relu, void* stream) {
+  return cp_conv_mfma_forward_strided(xs, cs, nsrc, wperm, bias, residual, out, B, H, W, Cout, taps, 1, relu, stream);
 }
 
 int cp_conv3x3_mfma_forward(const float* x, const void* wperm, const float* bias, const float* residual, float* out,

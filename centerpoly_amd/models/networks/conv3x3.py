@@ -68,16 +68,21 @@ def _launch(x, wp, bias, residual, cout, relu, taps=9):
 
 
 def conv_infer(xs, owner, w, bias=None, residual=None, relu=False, conv=None, key="_mfma_wperm"):
-    """Inference: 3x3 / pad 1 or 1x1 convolution (stride 1) of the channel concatenation of `xs` -- read in place,
+    """Inference: 3x3 / pad 1 (stride 1 or 2) or 1x1 (stride 1) convolution of the channel concatenation of `xs` -- read in place,
     no torch.cat -- with the (folded) weight `w`, + bias + residual + ReLU in the kernel's epilogue.  The permuted
     weights are cached on `owner` (under `key`) for as long as `w` is the same, unmodified tensor.  `conv`, when
     given, is the module whose geometry must be the kernel's.  Returns None when the shape is not the kernel's."""
     k = tuple(w.shape[2:])
     if not _ENABLED or k not in ((1, 1), (3, 3)):
         return None
-    if conv is not None and not (conv.stride == (1, 1) and conv.padding == (k[0] // 2, k[0] // 2)
-                                 and conv.dilation == (1, 1) and conv.groups == 1 and conv.padding_mode == "zeros"):
-        return None
+    stride = 1
+    if conv is not None:
+        if not (conv.stride in ((1, 1), (2, 2)) and conv.padding == (k[0] // 2, k[0] // 2)
+                and conv.dilation == (1, 1) and conv.groups == 1 and conv.padding_mode == "zeros"):
+            return None
+        stride = conv.stride[0]
+        if stride == 2 and k != (3, 3):
+            return None
     x0 = xs[0]
     if not all(x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[0] == x0.shape[0]
                and x.shape[2:] == x0.shape[2:] for x in xs) or len(xs) > 4:
@@ -85,10 +90,11 @@ def conv_infer(xs, owner, w, bias=None, residual=None, relu=False, conv=None, ke
     cs = [x.shape[1] for x in xs]
     cin, cout = sum(cs), w.shape[0]
     B, _, H, W = x0.shape
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
     L = _C.lib()
     if cin != w.shape[1] or cin < MIN_CIN or (len(xs) > 1 and any(c % 32 for c in cs)) \
             or not all(L.cp_conv3x3_mfma_supported(c, cout, H, W) for c in cs) \
-            or _workgroups(B, cout, H, W) < MIN_WORKGROUPS or (residual is not None and not residual.is_contiguous()):
+            or _workgroups(B, cout, Ho, Wo) < MIN_WORKGROUPS or (residual is not None and not residual.is_contiguous()):
         return None
     taps = k[0] * k[1]
     cache = owner.__dict__.get(key)
@@ -99,13 +105,14 @@ def conv_infer(xs, owner, w, bias=None, residual=None, relu=False, conv=None, ke
         cache = (w, w._version, wp)
         owner.__dict__[key] = cache
     xs = [x.contiguous() for x in xs]
-    out = torch.empty((B, cout, H, W), dtype=torch.float32, device=x0.device)
+    out = torch.empty((B, cout, Ho, Wo), dtype=torch.float32, device=x0.device)
     ptrs = (_C.c_void_p * len(xs))(*[x.data_ptr() for x in xs])
     chans = (_C.c_int32 * len(xs))(*cs)
-    tag = "conv3x3_fwd" if taps == 9 else "conv1x1_fwd"
+    tag = "conv3x3_fwd" if taps == 9 and stride == 1 else ("conv3x3s2_fwd" if taps == 9 else "conv1x1_fwd")
     end = _C.kernel_timer.start((tag, cin, cout, H, W, B)) if _C.kernel_timer is not None else None
-    _C.check(L.cp_conv_mfma_forward(ptrs, chans, len(xs), _C.ptr(cache[2]), _C.ptr(bias), _C.ptr(residual), _C.ptr(out),
-                                    B, H, W, cout, taps, 1 if relu else 0, _C.stream()), "cp_conv_mfma_forward")
+    _C.check(L.cp_conv_mfma_forward_strided(ptrs, chans, len(xs), _C.ptr(cache[2]), _C.ptr(bias), _C.ptr(residual),
+                                            _C.ptr(out), B, H, W, cout, taps, stride, 1 if relu else 0, _C.stream()),
+             "cp_conv_mfma_forward_strided")
     if end is not None:
         end.record()
     return out

@@ -199,6 +199,11 @@ int cp_conv_mfma_prepare(const float* weight, int32_t Cin, int32_t Cout, int32_t
 int cp_conv_mfma_forward(const float* const* xs, const int32_t* cs, int32_t nsrc, const void* wperm, const float* bias,
                          const float* residual, float* out, int32_t B, int32_t H, int32_t W, int32_t Cout,
                          int32_t taps, int32_t relu, void* stream);
+/* the same with a stride: 1, or 2 for the 3x3 form (the first convolution of DLA levels 2-5, pose_dla_dcn.py:38-46);
+ * out is [B][Cout][(H - 1) / stride + 1][(W - 1) / stride + 1] */
+int cp_conv_mfma_forward_strided(const float* const* xs, const int32_t* cs, int32_t nsrc, const void* wperm,
+                                 const float* bias, const float* residual, float* out, int32_t B, int32_t H, int32_t W,
+                                 int32_t Cout, int32_t taps, int32_t stride, int32_t relu, void* stream);
 
 /* Weight gradient of the same convolution, same arithmetic (what the reference gets from cuDNN's backward-filter):
  *   gw[co][ci][ky][kx] += sum_{b,y,x} go[b][co][y][x] * x[b][ci][y - 1 + ky][x - 1 + kx]

@@ -279,3 +279,31 @@ def test_1x1_weight_gradient_and_autograd(shape):
         yd = F.conv2d(xd, wd)
         gxd, gwd = torch.autograd.grad(yd, (xd, wd), go.double())
         assert _rel(y, yd.detach()) <= TOL and _rel(gx, gxd) <= TOL and _rel(gwa, gwd) <= TOL
+
+
+@pytest.mark.parametrize("shape", [(2, 32, 64, 40, 72), (1, 64, 128, 17, 33), (1, 128, 256, 64, 128), (2, 256, 48, 9, 31),
+                                   (1, 27, 64, 12, 130), (1, 64, 256, 128, 512), (1, 128, 256, 256, 256)],
+                         ids=["32->64", "64->128", "128->256", "256->48", "27->64", "64->256 wide tiles", "hourglass pre"])
+def test_stride_2_forward(shape):
+    """The stride-2 3x3 form (first convolution of DLA levels 2-5): odd and even map sizes, ragged channels."""
+    B, ci, co, H, W = shape
+    L = _C.lib()
+    x, w = _t("s2x%s" % (shape,), (B, ci, H, W)), _t("s2w%s" % (shape,), (co, ci, 3, 3), 0.05)
+    bias = _t("s2b", (co,))
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    res = _t("s2r%s" % (shape,), (B, co, Ho, Wo))
+    wp = torch.empty(L.cp_conv_mfma_weight_bytes(ci, co, 9), dtype=torch.uint8, device=DEV)
+    _C.check(L.cp_conv_mfma_prepare(P(w), ci, co, 9, 0, P(wp), _C.stream()), "prepare")
+    out = torch.full((B, co, Ho, Wo), float("nan"), device=DEV)
+    ptrs, chans = (ctypes.c_void_p * 1)(x.data_ptr()), (ctypes.c_int32 * 1)(ci)
+    _C.check(L.cp_conv_mfma_forward_strided(ptrs, chans, 1, P(wp), P(bias), P(res), P(out), B, H, W, co, 9, 2, 1,
+                                            _C.stream()), "forward")
+    ref = F.relu(F.conv2d(x.double(), w.double(), bias.double(), stride=2, padding=1) + res.double())
+    assert tuple(ref.shape) == tuple(out.shape)
+    assert torch.isfinite(out).all() and _rel(out, ref) <= TOL
+    out2 = torch.full((B, co, Ho, Wo), float("nan"), device=DEV)
+    _C.check(L.cp_conv_mfma_forward_strided(ptrs, chans, 1, P(wp), P(bias), P(res), P(out2), B, H, W, co, 9, 2, 1,
+                                            _C.stream()), "forward")
+    assert torch.equal(out, out2)                         # fixed order, no atomics: bit-identical reruns
+    assert L.cp_conv_mfma_forward_strided(ptrs, chans, 1, P(wp), None, None, P(out), B, H, W, co, 1, 2, 0,
+                                          _C.stream()) == -2      # stride 2 only in the 3x3 form
