@@ -27,13 +27,21 @@ def _workgroups(B, cout, H, W):
     return B * ((W + 31) // 32) * ((H + 3) // 4) * ((cout + 31) // 32)
 
 
+def _fills(B, cin, cout, H, W):
+    """Enough workgroups for the chip -- or, for deep inputs, enough for the in-workgroup K split (4 x 4 waves per
+    workgroup) to keep it busy: the 27-channel offset convolutions of the deep DCN layers, 16-64 workgroups, still
+    beat the library there (256 -> 27 @64x128: 22 us against 49)."""
+    n = _workgroups(B, cout, H, W)
+    return n >= MIN_WORKGROUPS or (cin >= 256 and n >= 16)
+
+
 def usable_shape(x, cout):
     """True when a 3x3 / stride 1 / pad 1 convolution of x to `cout` channels is a launch of the MFMA kernel."""
     if not (_ENABLED and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4):
         return False
     B, cin, H, W = x.shape
     return cin >= MIN_CIN and bool(_C.lib().cp_conv3x3_mfma_supported(cin, cout, H, W)) \
-        and _workgroups(B, cout, H, W) >= MIN_WORKGROUPS
+        and _fills(B, cin, cout, H, W)
 
 
 def usable(conv, x):
@@ -94,7 +102,7 @@ def conv_infer(xs, owner, w, bias=None, residual=None, relu=False, conv=None, ke
     L = _C.lib()
     if cin != w.shape[1] or cin < MIN_CIN or (len(xs) > 1 and any(c % 32 for c in cs)) \
             or not all(L.cp_conv3x3_mfma_supported(c, cout, H, W) for c in cs) \
-            or _workgroups(B, cout, Ho, Wo) < MIN_WORKGROUPS or (residual is not None and not residual.is_contiguous()):
+            or not _fills(B, cin, cout, Ho, Wo) or (residual is not None and not residual.is_contiguous()):
         return None
     taps = k[0] * k[1]
     cache = owner.__dict__.get(key)

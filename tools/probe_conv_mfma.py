@@ -74,7 +74,7 @@ if os.environ.get("PROBE_WGRAD", "1") == "1":
                   (8, 64, 256, 96, 320)]:
         run_wgrad(*shape)
 
-for shape in [(1, 32, 16, 8, 32), (2, 64, 27, 24, 80), (4, 64, 256, 256, 512), (1, 64, 256, 256, 512), (4, 64, 27, 256, 512), (1, 128, 128, 128, 256), (1, 256, 256, 64, 128), (1, 512, 512, 32, 64), (1, 64, 27, 256, 512), (1, 128, 27, 128, 256), (1, 256, 27, 64, 128),
+for shape in [(1, 32, 16, 8, 32), (2, 64, 27, 24, 80), (4, 64, 256, 256, 512), (1, 64, 256, 256, 512), (4, 64, 27, 256, 512), (1, 128, 128, 128, 256), (1, 256, 256, 64, 128), (1, 512, 512, 32, 64), (1, 64, 27, 256, 512), (1, 128, 27, 128, 256), (1, 256, 27, 64, 128), (1, 512, 27, 32, 64),
               (4, 64, 64, 128, 256), (4, 128, 128, 64, 128), (4, 256, 256, 32, 64), (4, 512, 512, 16, 32),
               (1, 64, 1024, 256, 512)]:
     run(*shape)
