@@ -1040,3 +1040,30 @@ def test_direct_conv_training_function_gradients():
                 assert (got - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()
             else:
                 torch.testing.assert_close(got, ref, rtol=1e-4, atol=1e-4)
+
+
+def test_hip_graph_replay_of_an_inference_step():
+    """utils/hip_graph.GraphedStep: the captured step (library convolutions, the hand-written kernels launched
+    through ctypes on torch's current stream, decode) replays to the eager step's result, also after the static
+    input has been rewritten in place."""
+    from centerpoly_amd.models.decode import polydet_decode
+    from centerpoly_amd.models.model import create_model
+    from centerpoly_amd.utils.hip_graph import GraphedStep
+    heads = {"hm": 8, "poly": 32, "pseudo_depth": 1, "reg": 2}
+    torch.manual_seed(5)
+    model = create_model("dla_34", heads, 256).to(DEV).eval()
+    model.prepare_inference()
+    x = g(synth.normal("graph/x0", (1, 3, 256, 512)))
+
+    def step():
+        with torch.no_grad():
+            out = model(x)[-1]
+            return polydet_decode(out["hm"].sigmoid_(), out["poly"], out["pseudo_depth"], reg=out["reg"], K=32)
+
+    ref0 = step().clone()
+    gs = GraphedStep(step)
+    assert torch.equal(gs(), ref0)
+    x.copy_(g(synth.normal("graph/x1", (1, 3, 256, 512))))      # new image into the static input
+    ref1 = step().clone()
+    assert not torch.equal(ref0, ref1)
+    assert torch.equal(gs(), ref1)
