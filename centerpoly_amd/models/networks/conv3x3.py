@@ -45,11 +45,17 @@ def usable_shape(x, cout):
 
 
 def usable(conv, x):
-    """True when conv(x) (without bias) is a launch of the MFMA kernel: 3x3 / pad 1 or 1x1, stride 1."""
+    """True when conv(x) (without bias) is a launch of the MFMA kernel: 3x3 / pad 1 (stride 1 or 2) or 1x1 (stride 1)."""
     k = conv.kernel_size
-    return (k in ((3, 3), (1, 1)) and conv.stride == (1, 1) and conv.padding == (k[0] // 2, k[0] // 2)
-            and conv.dilation == (1, 1) and conv.groups == 1 and conv.padding_mode == "zeros"
-            and usable_shape(x, conv.out_channels))
+    if not (k in ((3, 3), (1, 1)) and conv.padding == (k[0] // 2, k[0] // 2) and conv.dilation == (1, 1)
+            and conv.groups == 1 and conv.padding_mode == "zeros"):
+        return False
+    if conv.stride == (1, 1):
+        return usable_shape(x, conv.out_channels)
+    if conv.stride == (2, 2) and k == (3, 3) and x.dim() == 4:         # forward only; gradients from the library
+        B, cin, H, W = x.shape
+        return usable_shape(x, conv.out_channels) and _fills(B, cin, conv.out_channels, (H - 1) // 2 + 1, (W - 1) // 2 + 1)
+    return False
 
 
 def _prepare(weight, cin, cout, transposed):
@@ -61,15 +67,15 @@ def _prepare(weight, cin, cout, transposed):
     return wp
 
 
-def _launch(x, wp, bias, residual, cout, relu, taps=9):
+def _launch(x, wp, bias, residual, cout, relu, taps=9, stride=1):
     B, cin, H, W = x.shape
-    out = torch.empty((B, cout, H, W), dtype=torch.float32, device=x.device)
-    tag = "conv3x3_fwd" if taps == 9 else "conv1x1_fwd"
+    out = torch.empty((B, cout, (H - 1) // stride + 1, (W - 1) // stride + 1), dtype=torch.float32, device=x.device)
+    tag = ("conv3x3_fwd" if stride == 1 else "conv3x3s2_fwd") if taps == 9 else "conv1x1_fwd"
     end = _C.kernel_timer.start((tag, cin, cout, H, W, B)) if _C.kernel_timer is not None else None
     ptrs, chans = (_C.c_void_p * 1)(x.data_ptr()), (_C.c_int32 * 1)(cin)
-    _C.check(_C.lib().cp_conv_mfma_forward(ptrs, chans, 1, _C.ptr(wp), _C.ptr(bias), _C.ptr(residual), _C.ptr(out),
-                                           B, H, W, cout, taps, 1 if relu else 0, _C.stream()),
-             "cp_conv_mfma_forward")
+    _C.check(_C.lib().cp_conv_mfma_forward_strided(ptrs, chans, 1, _C.ptr(wp), _C.ptr(bias), _C.ptr(residual),
+                                                   _C.ptr(out), B, H, W, cout, taps, stride, 1 if relu else 0,
+                                                   _C.stream()), "cp_conv_mfma_forward_strided")
     if end is not None:
         end.record()
     return out
@@ -136,16 +142,24 @@ class _Conv3x3Fn(torch.autograd.Function):
     over grad_out with the transposed, flipped weights); weight gradient by cp_conv3x3_mfma_wgrad."""
 
     @staticmethod
-    def forward(ctx, x, weight):
+    def forward(ctx, x, weight, stride=1):
         ctx.save_for_backward(x, weight)
+        ctx.stride = stride
         cout, cin = weight.shape[0], weight.shape[1]
-        return _launch(x, _prepare(weight, cin, cout, False), None, None, cout, False, weight.shape[2] * weight.shape[3])
+        return _launch(x, _prepare(weight, cin, cout, False), None, None, cout, False, weight.shape[2] * weight.shape[3],
+                       stride)
 
     @staticmethod
     def backward(ctx, go):
         x, weight = ctx.saved_tensors
-        return grads(x, weight, go.contiguous(), ctx.needs_input_grad[0], ctx.needs_input_grad[1],
-                     min_k=MIN_CIN)
+        go = go.contiguous()
+        if ctx.stride != 1:                           # stride 2: the kernel has the forward only
+            gx = torch.nn.grad.conv2d_input(x.shape, weight, go, stride=ctx.stride, padding=1) \
+                if ctx.needs_input_grad[0] else None
+            gw = torch.nn.grad.conv2d_weight(x, weight.shape, go, stride=ctx.stride, padding=1) \
+                if ctx.needs_input_grad[1] else None
+            return gx, gw, None
+        return grads(x, weight, go, ctx.needs_input_grad[0], ctx.needs_input_grad[1], min_k=MIN_CIN) + (None,)
 
 
 def mfma_enabled():
@@ -183,5 +197,5 @@ def grads(x, weight, go, want_x=True, want_w=True, min_k=1):
 def conv_raw(conv, x):
     """conv(x) WITHOUT its bias, differentiable: the MFMA kernel for its shapes, the library otherwise."""
     if usable(conv, x):
-        return _Conv3x3Fn.apply(x.contiguous(), conv.weight)
+        return _Conv3x3Fn.apply(x.contiguous(), conv.weight, conv.stride[0])
     return F.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation, conv.groups)

@@ -307,3 +307,19 @@ def test_stride_2_forward(shape):
     assert torch.equal(out, out2)                         # fixed order, no atomics: bit-identical reruns
     assert L.cp_conv_mfma_forward_strided(ptrs, chans, 1, P(wp), None, None, P(out), B, H, W, co, 1, 2, 0,
                                           _C.stream()) == -2      # stride 2 only in the 3x3 form
+
+
+def test_stride_2_autograd_wrapper():
+    """conv_raw on a stride-2 3x3 convolution: forward from the MFMA kernel, both gradients from the library."""
+    from centerpoly_amd.models.networks import conv3x3
+    conv = torch.nn.Conv2d(64, 128, 3, stride=2, padding=1, bias=False).to(DEV)
+    x = _t("s2ax", (4, 64, 64, 128)).requires_grad_(True)
+    assert conv3x3.usable(conv, x)
+    y = conv3x3.conv_raw(conv, x)
+    assert tuple(y.shape) == (4, 128, 32, 64)
+    go = _t("s2ago", tuple(y.shape))
+    gx, gw = torch.autograd.grad(y, (x, conv.weight), go)
+    xd, wd = x.detach().double().requires_grad_(True), conv.weight.detach().double().requires_grad_(True)
+    yd = F.conv2d(xd, wd, stride=2, padding=1)
+    gxd, gwd = torch.autograd.grad(yd, (xd, wd), go.double())
+    assert _rel(y, yd.detach()) <= TOL and _rel(gx, gxd) <= 1e-4 and _rel(gw, gwd) <= 1e-4
