@@ -290,6 +290,27 @@ def conv_roofline(summary, tag="conv3x3_fwd"):
     return hbm, split_bf16_roofline(common, alg_flops, avg_s)
 
 
+def heads_roofline(summary):
+    """The fused heads launch (3x3 convolution + bias + ReLU + 1x1 convolution of all heads, csrc/heads_fused.hip):
+    algorithmic flops of both stages, bytes = input + the heads' outputs + weights (the head_conv-channel
+    intermediate never reaches memory)."""
+    keys = [k for k in (summary or {}) if k[0] == "heads_fused"]
+    if not keys:
+        return None, None
+    key = max(keys, key=lambda k: summary[k]["avg_ms"] * summary[k]["launches"])
+    _, cin, ctot, h, w, nb, hc, cout_sum = key
+    avg_s = summary[key]["avg_ms"] * 1e-3
+    alg_flops = 2.0 * (9 * cin * ctot + hc * cout_sum) * h * w * nb
+    alg_bytes = 4.0 * (nb * (cin + cout_sum) * h * w + 9 * cin * ctot + hc * cout_sum)
+    common = {"traffic": None, "traffic_source": "not measured for this kernel",
+              "kernel": "fused heads: conv3x3 %d->%d + ReLU + conv1x1 ->%d @%dx%d" % (cin, ctot, cout_sum, h, w)
+                        + (" x%d images" % nb if nb != 1 else ""),
+              "avg_launch_us": avg_s * 1e6, "launches": summary[key]["launches"]}
+    hbm = dict(common, bound="hbm", achieved=alg_bytes / avg_s / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
+               frac=alg_bytes / avg_s / 1e9 / HBM_PEAK_GBS, algorithmic_bytes_per_launch=alg_bytes)
+    return hbm, split_bf16_roofline(common, alg_flops, avg_s)
+
+
 # --------------------------------------------------------------------- legs ---
 def infer_leg(args, dev, world, arch="dla_34", heads=None, rep="cartesian", steps=None, warmup=None,
               offset_weight_scale=0.5, tag="infer"):
@@ -323,7 +344,7 @@ def infer_leg(args, dev, world, arch="dla_34", heads=None, rep="cartesian", step
     probe = _C.kernel_timer.summary()
     _C.kernel_timer = None
     watch = set()
-    for fam in ("dcn_fwd", "conv3x3_fwd"):
+    for fam in ("dcn_fwd", "conv3x3_fwd", "heads_fused"):
         keys = [k for k in probe if k[0] == fam]
         if keys:
             watch.add(max(keys, key=lambda k: probe[k]["avg_ms"] * probe[k]["launches"]))
@@ -631,6 +652,7 @@ def main(argv=None):
         meta = summary.pop("__meta__")
         hbm, mfma = dcn_roofline(summary)
         chbm, cmfma = conv_roofline(summary)
+        hhbm, hmfma = heads_roofline(summary)
         if mfma is None:                                   # Hourglass: no DCN, the 3x3 convolution dominates
             hbm, mfma = chbm, cmfma
         line.update({
@@ -643,6 +665,7 @@ def main(argv=None):
             # the HBM fraction of the same launch is reported beside it
             "roofline": mfma, "roofline_hbm": hbm,
             "roofline_conv3x3": cmfma, "roofline_conv3x3_hbm": chbm,
+            "roofline_heads": hmfma, "roofline_heads_hbm": hhbm,
             "dcn_layers_ms": {"%d->%d@%dx%d" % k[1:5]: round(v["avg_ms"], 4) for k, v in summary.items()
                               if k[0].startswith("dcn")},
             "conv3x3_ms_per_image": round(meta["conv3x3_ms_per_image"], 4),

@@ -15,7 +15,7 @@ import torch.nn.functional as F
 
 from ... import _C
 from .conv3x3 import conv3x3_infer
-from .pose_dla_dcn import _conv_folded, _fold_conv_bn, _use_folded, bn_act, conv_train
+from .pose_dla_dcn import _conv_folded, _fold_conv_bn, _use_folded, bn_act, conv_train, heads_fused_infer
 
 # Inference (`prepare_inference()`): every BatchNorm is folded into its convolution (weights scaled,
 # shift as a bias) and each conv is followed by ONE fused in-place pass -- + bias (+ residual) (+ ReLU),
@@ -191,6 +191,9 @@ class exkp(nn.Module):
 
     def _heads_fast(self, s, cnv):
         w, b, tails = self._heads_cat[s]
+        out = heads_fused_infer(self, "_heads_fused_cache%d" % s, cnv, w, b, tails, list(self.heads))
+        if out is not None:
+            return out
         y = conv3x3_infer(cnv, self, w, key="_heads_wperm%d" % s)
         if y is None:
             y = F.conv2d(cnv, w, None, padding=1)

@@ -571,6 +571,56 @@ class DLAUp(nn.Module):
         return out
 
 
+def heads_fused_infer(owner, key, feat, w, b, tails, names):
+    """All heads of one output stage as ONE kernel (cp_heads_fused_forward): 3x3 convolution + bias + ReLU + 1x1
+    convolution + bias, the nheads x head_conv-channel intermediate never leaves the accumulator registers.
+    w, b: the heads' 3x3 weights / biases concatenated along the output channels; tails: per head (1x1 weight
+    transposed [hc][co], 1x1 bias or None, hc, co).  The permuted weights are cached on `owner` under `key`.
+    None when the shapes are not the kernel's (more than 4 heads, a head wider than 64 outputs, head_conv not a
+    multiple of 64, input channels not a multiple of 32)."""
+    if os.environ.get("CP_HEADS_FUSED", "1") == "0" or not conv3x3.mfma_enabled():
+        return None
+    hcs = {t[2] for t in tails}
+    B, cin, H, W = feat.shape
+    if not (feat.is_cuda and feat.dtype == torch.float32 and len(tails) <= 4 and len(hcs) == 1 and cin % 32 == 0
+            and all(t[3] <= 64 for t in tails)):
+        return None
+    hc = hcs.pop()
+    if hc % 64 != 0:
+        return None
+    L = _C.lib()
+    cache = owner.__dict__.get(key)
+    if cache is None or cache[0] is not w or cache[1] != w._version:
+        wp1 = conv3x3._prepare(w, cin, w.shape[0], False)
+        w2p = []
+        for (w_t, b2, _, co) in tails:
+            w2 = w_t.t().contiguous()                       # [co][hc]
+            buf = torch.empty(L.cp_heads_fused_w2_bytes(hc), dtype=torch.uint8, device=w.device)
+            _C.check(L.cp_heads_fused_prepare_w2(_C.ptr(w2), co, hc, _C.ptr(buf), _C.stream()),
+                     "cp_heads_fused_prepare_w2")
+            w2p.append(buf)
+        cache = (w, w._version, wp1, w2p)
+        owner.__dict__[key] = cache
+    feat = feat.contiguous()
+    outs = [torch.empty((B, t[3], H, W), dtype=torch.float32, device=feat.device) for t in tails]
+    n = len(tails)
+    vp = _C.c_void_p
+    w2arr = (vp * n)(*[t.data_ptr() for t in cache[3]])
+    b2arr = (vp * n)(*[(t[1].data_ptr() if t[1] is not None else None) for t in tails])
+    oarr = (vp * n)(*[o.data_ptr() for o in outs])
+    carr = (_C.c_int32 * n)(*[t[3] for t in tails])
+    end = _C.kernel_timer.start(("heads_fused", cin, w.shape[0], H, W, B, hc, sum(t[3] for t in tails))) \
+        if _C.kernel_timer is not None else None
+    rc = L.cp_heads_fused_forward(_C.ptr(feat), _C.ptr(cache[2]), _C.ptr(b), w2arr, b2arr, oarr, carr, n, B, cin, H, W,
+                                  hc, _C.stream())
+    if end is not None:
+        end.record()
+    if rc == -2:
+        return None
+    _C.check(rc, "cp_heads_fused_forward")
+    return dict(zip(names, outs))
+
+
 class DLASeg(nn.Module):
     def __init__(self, base_name, heads, pretrained, down_ratio, final_kernel, last_level,
                  head_conv, out_channel=0):
@@ -632,12 +682,19 @@ class DLASeg(nn.Module):
                                        torch.cat([fc[0].bias for fc in fcs], 0).contiguous(), tails)
         return self
 
+    def _heads_fused(self, feat):
+        w, b, tails = self._heads_cat
+        return heads_fused_infer(self, "_heads_fused_cache", feat, w, b, tails, list(self.heads))
+
     def _heads_fast(self, feat):
         """All heads' conv3x3 as ONE library convolution (they share the input); each head's
         bias + ReLU + 1x1 convolution is then one streaming kernel over its channel slice of the
         raw result (cp_conv1x1_act_forward) -- the 4x256-channel tensor is read once instead of
         going through a bias/ReLU pass and a GEMM with a handful of output rows."""
         w, b, tails = self._heads_cat
+        out = self._heads_fused(feat)
+        if out is not None:
+            return out
         y = conv3x3_infer(feat, self, w, key="_heads_wperm")
         if y is None:
             y = F.conv2d(feat, w, None, padding=1)
@@ -659,7 +716,7 @@ class DLASeg(nn.Module):
             for m in self.modules():
                 if hasattr(m, "_folded"):
                     m._folded = None
-                for k in [k for k in m.__dict__ if k.startswith(("_mfma_wperm", "_heads_wperm", "_dcn_fwd_ws"))]:
+                for k in [k for k in m.__dict__ if k.startswith(("_mfma_wperm", "_heads_wperm", "_heads_fused", "_dcn_fwd_ws"))]:
                     del m.__dict__[k]          # permuted inference weights / DCN workspaces of the folded tensors
             self._heads_cat = None
         return super().train(mode)

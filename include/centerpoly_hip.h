@@ -224,6 +224,19 @@ int cp_conv_direct_wgrad_supported(int32_t Cin, int32_t Cout, int32_t k, int32_t
 int cp_conv_direct_wgrad(const float* x, const float* go, float* gw, int32_t B, int32_t Cin, int32_t H, int32_t W,
                          int32_t Cout, int32_t k, int32_t stride, int32_t pad, void* stream);
 
+/* The detection heads at inference as ONE kernel (the `fc` Sequentials of DLASeg over their shared input,
+ * src/lib/models/networks/pose_dla_dcn.py:445-462,479-481):
+ *   out[h][b][o][p] = b2[h][o] + sum_c w2[h][o][c] * relu(b1[h * HC + c] + conv3x3(x, w1)[b][h * HC + c][p])
+ * w1 = the heads' 3x3 weights concatenated along the output channels ([nheads * HC][Cin][3][3]) and prepared by
+ * cp_conv_mfma_prepare(taps 9) into wperm1; w2[h] = the head's 1x1 weight [cout[h]][HC] prepared by
+ * cp_heads_fused_prepare_w2.  The HC-channel intermediate stays in accumulator registers (split-bf16 x3 on both
+ * stages).  nheads <= 4, cout[h] <= 64, HC % 64 == 0, Cin % 32 == 0; otherwise CP_EUNSUPPORTED. */
+size_t cp_heads_fused_w2_bytes(int32_t head_conv);
+int cp_heads_fused_prepare_w2(const float* w2, int32_t cout, int32_t head_conv, void* w2perm, void* stream);
+int cp_heads_fused_forward(const float* x, const void* wperm1, const float* b1, const void* const* w2perm,
+                           const float* const* b2, float* const* out, const int32_t* cout, int32_t nheads, int32_t B,
+                           int32_t Cin, int32_t H, int32_t W, int32_t head_conv, void* stream);
+
 /* Output stage of a detection head at inference (the `fc` Sequential of DLASeg,
  * src/lib/models/networks/pose_dla_dcn.py:445-462: Conv2d 3x3 + bias -> ReLU -> Conv2d 1x1 + bias),
  * everything after the 3x3 convolution's matrix product, one pass:

@@ -323,3 +323,36 @@ def test_stride_2_autograd_wrapper():
     yd = F.conv2d(xd, wd, stride=2, padding=1)
     gxd, gwd = torch.autograd.grad(yd, (xd, wd), go.double())
     assert _rel(y, yd.detach()) <= TOL and _rel(gx, gxd) <= 1e-4 and _rel(gw, gwd) <= 1e-4
+
+
+@pytest.mark.parametrize("cfg", [((8, 32, 1, 2), 256, 64, 40, 72), ((8, 32), 128, 96, 17, 33), ((3,), 64, 32, 8, 32),
+                                 ((8, 48, 1, 2), 256, 256, 16, 64), ((64, 2), 64, 32, 9, 31)],
+                         ids=["polydet heads", "two heads hc128", "one head hc64", "hourglass polar heads (48)", "64 classes"])
+def test_fused_heads_kernel(cfg):
+    """cp_heads_fused_forward: conv3x3 + bias + ReLU + conv1x1 + bias of up to four heads in one launch against
+    float64 torch (ragged map sizes, 1 .. 32 classes, head_conv 64 / 128 / 256)."""
+    couts, hc, cin, H, W = cfg
+    L = _C.lib()
+    B, nh = 2, len(couts)
+    x = _t("hf/x%s" % (cfg,), (B, cin, H, W))
+    w1 = _t("hf/w1%s" % (cfg,), (nh * hc, cin, 3, 3), 0.05)
+    b1 = _t("hf/b1%s" % (cfg,), (nh * hc,))
+    w2 = [_t("hf/w2_%d%s" % (i, cfg), (co, hc), 0.1) for i, co in enumerate(couts)]
+    b2 = [_t("hf/b2_%d%s" % (i, cfg), (co,)) for i, co in enumerate(couts)]
+    wp1 = torch.empty(L.cp_conv_mfma_weight_bytes(cin, nh * hc, 9), dtype=torch.uint8, device=DEV)
+    _C.check(L.cp_conv_mfma_prepare(P(w1), cin, nh * hc, 9, 0, P(wp1), _C.stream()), "prepare")
+    w2p = []
+    for w, co in zip(w2, couts):
+        buf = torch.empty(L.cp_heads_fused_w2_bytes(hc), dtype=torch.uint8, device=DEV)
+        _C.check(L.cp_heads_fused_prepare_w2(P(w), co, hc, P(buf), _C.stream()), "prepare_w2")
+        w2p.append(buf)
+    outs = [torch.full((B, co, H, W), float("nan"), device=DEV) for co in couts]
+    vp = ctypes.c_void_p
+    rc = L.cp_heads_fused_forward(P(x), P(wp1), P(b1), (vp * nh)(*[t.data_ptr() for t in w2p]),
+                                  (vp * nh)(*[t.data_ptr() for t in b2]), (vp * nh)(*[t.data_ptr() for t in outs]),
+                                  (ctypes.c_int32 * nh)(*couts), nh, B, cin, H, W, hc, _C.stream())
+    assert rc == 0
+    hid = F.relu(F.conv2d(x.double(), w1.double(), b1.double(), padding=1))
+    for i, co in enumerate(couts):
+        ref = F.conv2d(hid[:, i * hc:(i + 1) * hc], w2[i].double().view(co, hc, 1, 1), b2[i].double())
+        assert torch.isfinite(outs[i]).all() and _rel(outs[i], ref) <= TOL, i
