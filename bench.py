@@ -188,6 +188,7 @@ def timed(fn, steps, warmup, world, tag=""):
 
 
 CONV_SOURCES = ("conv_mfma.hip", "cp_common.h")
+HEADS_SOURCES = ("heads_fused.hip", "cp_common.h")
 
 
 def kernel_revision(sources=("dcn_fwd.hip", "cp_common.h")):
@@ -302,7 +303,8 @@ def heads_roofline(summary):
     avg_s = summary[key]["avg_ms"] * 1e-3
     alg_flops = 2.0 * (9 * cin * ctot + hc * cout_sum) * h * w * nb
     alg_bytes = 4.0 * (nb * (cin + cout_sum) * h * w + 9 * cin * ctot + hc * cout_sum)
-    common = {"traffic": None, "traffic_source": "not measured for this kernel",
+    traffic, traffic_src = measured_traffic(cin, ctot, h, w, nb, "heads_fused_pmc.json", HEADS_SOURCES)
+    common = {"traffic": traffic, "traffic_source": traffic_src,
               "kernel": "fused heads: conv3x3 %d->%d + ReLU + conv1x1 ->%d @%dx%d" % (cin, ctot, cout_sum, h, w)
                         + (" x%d images" % nb if nb != 1 else ""),
               "avg_launch_us": avg_s * 1e6, "launches": summary[key]["launches"]}

@@ -66,3 +66,21 @@ if len(sys.argv) > 4:
            "layers": layers, "_raw": raw}
     json.dump(out, open(sys.argv[4], "w"), indent=1)
     print(json.dumps(out))
+
+
+# ---- and for the fused heads launch (csrc/heads_fused.hip): 512 tiles x 4 heads x 256 threads ----
+if len(sys.argv) > 5:
+    fetch, write = avg(sys.argv[1], "FETCH_SIZE", "conv_heads_fused_kernel"), avg(sys.argv[2], "WRITE_SIZE", "conv_heads_fused_kernel")
+    layers, raw = {}, {}
+    for grid, shape in {512 * 4 * 256: (1, 64, 1024, 256, 512)}.items():
+        if grid in fetch and grid in write:
+            f, n = fetch[grid]
+            w, _ = write[grid]
+            layers["%dx%dx%dx%dx%d" % shape] = (2.0 * f + w) * 1024.0
+            raw["%dx%dx%dx%dx%d" % shape] = {"FETCH_SIZE_KB_avg": f, "WRITE_SIZE_KB_avg": w, "launches": n}
+    out = {"kernel_rev": bench.kernel_revision(bench.HEADS_SOURCES), "inputs": "bench.py infer leg", "command": out["command"],
+           "correction": "traffic = (2*FETCH_SIZE + WRITE_SIZE)*1024 bytes (gfx950: FETCH_SIZE reports half of a wide "
+                         "coalesced stream's bytes, WRITE_SIZE is exact)",
+           "layers": layers, "_raw": raw}
+    json.dump(out, open(sys.argv[5], "w"), indent=1)
+    print(json.dumps(out))

@@ -11,9 +11,10 @@ for c in FETCH_SIZE WRITE_SIZE; do
   rc=$?; echo "pass $c rc=$rc"
   if [ $rc -ne 0 ]; then tail -5 $out/$c.log; exit 1; fi
 done
-python3 tools/pmc_bench_traffic.py $out/FETCH_SIZE $out/WRITE_SIZE $out/dcn_fwd_pmc.json $out/conv_mfma_pmc.json
+python3 tools/pmc_bench_traffic.py $out/FETCH_SIZE $out/WRITE_SIZE $out/dcn_fwd_pmc.json $out/conv_mfma_pmc.json $out/heads_fused_pmc.json
 for c in FETCH_SIZE WRITE_SIZE; do
   f=$(find $out/$c -name "*counter_collection.csv" | head -1)
   (head -1 $f; grep dcn_fwd $f) > $out/r02_bench_dcn_fwd_pmc_$c.csv
   (head -1 $f; grep "conv_mfma_kernel<4, 2, 9" $f) > $out/r02_bench_conv_mfma_pmc_$c.csv
+  (head -1 $f; grep "conv_heads_fused_kernel" $f) > $out/r02_bench_heads_fused_pmc_$c.csv
 done
