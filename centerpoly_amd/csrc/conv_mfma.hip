@@ -427,7 +427,9 @@ template <int MTW, int TAPS>
 __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_kernel(WgArgs a) {
   constexpr int CO = 32 * MTW;
   constexpr int G_PLANE = CO * WG_GP, X_PLANE = WG_CI * WG_XP;                 // elements per half
-  constexpr int G_ITERS = CO * 32 / 512, X_UNITS = WG_CI * 60, X_ITERS = (X_UNITS + 511) / 512;
+  // staged input per channel: 6 rows x 10 float4 (halo for the 3x3 taps); the 1x1 form needs only the tile's own 4 x 8
+  constexpr int XROWS = TAPS == 9 ? 6 : 4, XQ = TAPS == 9 ? 10 : 8;
+  constexpr int G_ITERS = CO * 32 / 512, X_UNITS = WG_CI * XROWS * XQ, X_ITERS = (X_UNITS + 511) / 512;
   constexpr int STAGE_BYTES = (2 * G_PLANE + 2 * X_PLANE) * 2;
   constexpr int OP = WG_CI * TAPS + 1, OUT_BYTES = 32 * OP * 4;
   constexpr int SMEM = STAGE_BYTES > OUT_BYTES ? STAGE_BYTES : OUT_BYTES;
@@ -460,7 +462,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_kernel(WgArgs a) {
 #pragma unroll
   for (int i = 0; i < X_ITERS; ++i) {
     const int u = tid + i * 512;
-    const int q = u % 10, rr = (u / 10) % 6, ci = u / 60;
+    const int q = u % XQ + (TAPS == 9 ? 0 : 1), rr = (u / XQ) % XROWS + (TAPS == 9 ? 0 : 1), ci = u / (XROWS * XQ);
     x_lds[i] = u < X_UNITS ? ci * WG_XP + rr * WG_XR + 4 + 4 * q : -1;
     x_rc[i] = (ci << 16) | (rr << 8) | (4 * q);
   }
