@@ -84,6 +84,8 @@ _SIGNATURES = {
     "cp_heads_fused_w2_bytes": (c_size_t, [c_int32]),
     "cp_heads_fused_prepare_w2": (c_int32, [_P, c_int32, c_int32, _P, _P]),
     "cp_heads_fused_forward": (c_int32, [_P, _P, _P, _P, _P, _P, _P] + [c_int32] * 6 + [_P]),
+    "cp_maxpool2x2_forward": (c_int32, [_P, _P] + [c_int32] * 4 + [_P]),
+    "cp_maxpool2x2_backward": (c_int32, [_P, _P, _P] + [c_int32] * 4 + [_P]),
     "cp_conv1x1_act_forward": (c_int32, [_P, c_int64, _P, c_int32, _P, _P, _P, c_int32, c_int32, c_int32, c_int64, _P]),
     "cp_soft_nms": (c_int32, [_P, c_int32, c_int32, c_float, c_float, c_float, c_int32]),
     "cp_polydet_decode_workspace_bytes": (c_size_t, [c_int32] * 5),

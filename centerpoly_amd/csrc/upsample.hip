@@ -273,3 +273,110 @@ extern "C" int cp_depthwise_up_backward(const float* x, const float* weight, con
   }
   return cp_launch_status();
 }
+
+// =====================================================================================================================
+// 2x2 / stride 2 max pooling of the DLA trees (`downsample = nn.MaxPool2d(stride, stride=stride)`,
+// src/lib/models/networks/pose_dla_dcn.py:186-187,203-204), forward and backward, bandwidth-bound streams.
+// out[b][c][y][x] = max of in[2y .. 2y+1][2x .. 2x+1] (floor mode: a trailing odd row / column is ignored); the
+// backward recomputes the arg-max from the input with torch's rule -- scan rows then columns, strict '>' (a NaN
+// wins), so the FIRST maximum of a tie takes the gradient (ReLU outputs tie at 0 all the time) -- and writes every
+// element of grad_in (no zero-fill, no index tensor).  One thread = two output pixels = one float4 of each input row.
+// =====================================================================================================================
+namespace {
+
+__device__ __forceinline__ int argmax4(float a, float b, float c, float d) {     // order: (0,0) (0,1) (1,0) (1,1)
+  int k = 0;
+  float m = a;
+  if (b > m || b != b) { m = b; k = 1; }
+  if (c > m || c != c) { m = c; k = 2; }
+  if (d > m || d != d) { m = d; k = 3; }
+  return k;                                           // (torch: val > max || isnan(val): the last NaN wins)
+}
+
+__global__ __launch_bounds__(256) void maxpool2_fwd_kernel(const float* __restrict__ x, float* __restrict__ out, int H, int W,
+                                                           int Ho, int Wo, long long planes) {
+  const int q = blockIdx.x * 256 + threadIdx.x;       // pair of output pixels in the row
+  const int y = blockIdx.y;
+  const long long pl = blockIdx.z;
+  const int xo = 2 * q;
+  if (xo >= Wo || pl >= planes) return;
+  const float* r0 = x + (pl * H + 2 * y) * W + 2 * xo;
+  const float* r1 = r0 + W;
+  float* o = out + (pl * Ho + y) * Wo + xo;
+  if (xo + 1 < Wo && (W & 3) == 0) {
+    const float4 a = *reinterpret_cast<const float4*>(r0), b = *reinterpret_cast<const float4*>(r1);
+    const float va[4] = {a.x, a.y, b.x, b.y}, vb[4] = {a.z, a.w, b.z, b.w};
+    o[0] = va[argmax4(va[0], va[1], va[2], va[3])];
+    o[1] = vb[argmax4(vb[0], vb[1], vb[2], vb[3])];
+  } else {
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      if (xo + e < Wo) {
+        const float v[4] = {r0[2 * e], r0[2 * e + 1], r1[2 * e], r1[2 * e + 1]};
+        o[e] = v[argmax4(v[0], v[1], v[2], v[3])];
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const float* __restrict__ x, const float* __restrict__ go,
+                                                           float* __restrict__ gx, int H, int W, int Ho, int Wo,
+                                                           long long planes) {
+  const int q = blockIdx.x * 256 + threadIdx.x;       // float4 of an input row (two output pixels), or the tail
+  const int yi = blockIdx.y;                          // input row pair index; yi == Ho: the trailing odd row
+  const long long pl = blockIdx.z;
+  if (pl >= planes) return;
+  if (yi >= Ho) {                                     // trailing odd input row: no window covers it
+    for (int xx = q; xx < W; xx += gridDim.x * 256) gx[(pl * H + (H - 1)) * W + xx] = 0.f;
+    return;
+  }
+  const int xo = 2 * q;
+  if (2 * xo >= W) return;
+  const float* r0 = x + (pl * H + 2 * yi) * W + 2 * xo;
+  const float* r1 = r0 + W;
+  float* g0 = gx + (pl * H + 2 * yi) * W + 2 * xo;
+  float* g1 = g0 + W;
+  const float* gp = go + (pl * Ho + yi) * Wo + xo;
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const int xin = 2 * (xo + e);
+    if (xin >= W) break;
+    if (xo + e < Wo) {
+      const float v[4] = {r0[2 * e], r0[2 * e + 1], r1[2 * e], r1[2 * e + 1]};
+      const int k = argmax4(v[0], v[1], v[2], v[3]);
+      const float gval = gp[e];
+      g0[2 * e] = k == 0 ? gval : 0.f;
+      g0[2 * e + 1] = k == 1 ? gval : 0.f;
+      g1[2 * e] = k == 2 ? gval : 0.f;
+      g1[2 * e + 1] = k == 3 ? gval : 0.f;
+    } else {                                          // trailing odd input column
+      g0[2 * e] = 0.f;
+      g1[2 * e] = 0.f;
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int cp_maxpool2x2_forward(const float* x, float* out, int32_t B, int32_t C, int32_t H, int32_t W, void* stream) {
+  CP_CHECK_ARG(x && out && B > 0 && C > 0 && H >= 2 && W >= 2);
+  const int Ho = H / 2, Wo = W / 2;
+  const long long planes = (long long)B * C;
+  if (planes > 65535 || Ho > 65535) return CP_EUNSUPPORTED;
+  const dim3 grid(((Wo + 1) / 2 + 255) / 256, Ho, (unsigned)planes);
+  hipLaunchKernelGGL(maxpool2_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, out, H, W, Ho, Wo, planes);
+  return cp_launch_status();
+}
+
+// grad_in [B][C][H][W] is overwritten (every element written).
+extern "C" int cp_maxpool2x2_backward(const float* x, const float* grad_out, float* grad_in, int32_t B, int32_t C, int32_t H,
+                                      int32_t W, void* stream) {
+  CP_CHECK_ARG(x && grad_out && grad_in && B > 0 && C > 0 && H >= 2 && W >= 2);
+  const int Ho = H / 2, Wo = W / 2;
+  const long long planes = (long long)B * C;
+  if (planes > 65535 || Ho + 1 > 65535) return CP_EUNSUPPORTED;
+  const dim3 grid(((W + 3) / 4 + 255) / 256, Ho + (H & 1), (unsigned)planes);
+  hipLaunchKernelGGL(maxpool2_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, grad_out, grad_in, H, W, Ho, Wo,
+                     planes);
+  return cp_launch_status();
+}

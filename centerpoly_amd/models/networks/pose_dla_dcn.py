@@ -165,6 +165,38 @@ def _conv_folded(x, conv, wb, relu=False, residual=None):
     return y
 
 
+# ---- 2x2 / stride 2 max pooling (the trees' `downsample`) --------------------------------------------
+class _MaxPool2x2Fn(torch.autograd.Function):
+    """MaxPool2d(2, 2) through cp_maxpool2x2_*: no index tensor; the backward recomputes the arg-max from x (torch's
+    tie rule) and writes every element of the gradient."""
+
+    @staticmethod
+    def forward(ctx, x):
+        B, C, H, W = x.shape
+        out = torch.empty((B, C, H // 2, W // 2), dtype=torch.float32, device=x.device)
+        _C.check(_C.lib().cp_maxpool2x2_forward(_C.ptr(x), _C.ptr(out), B, C, H, W, _C.stream()), "cp_maxpool2x2_forward")
+        ctx.save_for_backward(x)
+        return out
+
+    @staticmethod
+    def backward(ctx, go):
+        (x,) = ctx.saved_tensors
+        B, C, H, W = x.shape
+        gx = torch.empty_like(x)
+        _C.check(_C.lib().cp_maxpool2x2_backward(_C.ptr(x), _C.ptr(go.contiguous()), _C.ptr(gx), B, C, H, W,
+                                                 _C.stream()), "cp_maxpool2x2_backward")
+        return gx
+
+
+def downsample2(pool, x):
+    """pool(x) for the trees' MaxPool2d(2, 2): the HIP kernels on a device tensor, the module otherwise."""
+    if (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and pool.kernel_size in (2, (2, 2))
+            and pool.stride in (2, (2, 2)) and pool.padding in (0, (0, 0)) and not pool.ceil_mode
+            and x.shape[0] * x.shape[1] <= 65535 and x.shape[2] >= 2 and x.shape[3] >= 2):
+        return _MaxPool2x2Fn.apply(x.contiguous())
+    return pool(x)
+
+
 # ---- training-time fused conv-bias + ReLU (the heads' Conv2d(3x3, bias) -> ReLU) -----------
 class _BiasRelu(torch.autograd.Function):
     """y = relu(y_raw + bias[c]) in place on the convolution's raw output; backward is one pass
@@ -344,7 +376,7 @@ class Tree(nn.Module):
 
     def forward(self, x, residual=None, children=None):
         children = [] if children is None else children
-        bottom = x if self.downsample is None else self.downsample(x)
+        bottom = x if self.downsample is None else downsample2(self.downsample, x)
         if self.project is None:
             residual = bottom
         elif self.project_is_dead:

@@ -144,6 +144,13 @@ int cp_depthwise_up_backward(const float* x, const float* weight, const float* g
                              float* grad_x, float* grad_weight, int32_t B, int32_t C, int32_t H,
                              int32_t W, int32_t f, void* stream);
 
+/* 2x2 / stride 2 max pooling (floor mode) of the DLA trees' `downsample` (src/lib/models/networks/pose_dla_dcn.py:
+ * 186-187,203-204), torch's tie rule (first maximum in row-major order, NaN propagates).  The backward recomputes the
+ * arg-max from x and OVERWRITES grad_in (every element, also a trailing odd row / column). */
+int cp_maxpool2x2_forward(const float* x, float* out, int32_t B, int32_t C, int32_t H, int32_t W, void* stream);
+int cp_maxpool2x2_backward(const float* x, const float* grad_out, float* grad_in, int32_t B, int32_t C, int32_t H,
+                           int32_t W, void* stream);
+
 /* y <- act(y + bias[c] + residual) in place (fp32 NCHW, HW = H*W): the epilogue of a library
  * convolution whose BatchNorm was folded (inference).  bias / residual may be NULL. */
 int cp_bias_act_inplace(float* y, const float* bias, const float* residual, int32_t B, int32_t C,

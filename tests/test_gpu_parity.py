@@ -1067,3 +1067,22 @@ def test_hip_graph_replay_of_an_inference_step():
     ref1 = step().clone()
     assert not torch.equal(ref0, ref1)
     assert torch.equal(gs(), ref1)
+
+
+@pytest.mark.parametrize("shape", [(2, 16, 64, 128), (1, 3, 9, 7), (3, 5, 16, 30), (1, 2, 2, 2)],
+                         ids=["aligned", "odd rows and columns", "W % 4 != 0", "single window"])
+def test_maxpool2x2_forward_backward_match_torch(shape):
+    """cp_maxpool2x2_*: values and gradient routing equal torch's MaxPool2d(2, 2), ties included (ReLU-like input with
+    many equal zeros: the first maximum in row-major order takes the gradient)."""
+    import torch.nn.functional as F
+    from centerpoly_amd.models.networks.pose_dla_dcn import downsample2
+    x = torch.relu(g(synth.normal("pool/x%s" % (shape,), shape))).requires_grad_(True)    # ~half zeros -> ties
+    pool = torch.nn.MaxPool2d(2, stride=2)
+    y = downsample2(pool, x)
+    yr = F.max_pool2d(x.detach().clone().requires_grad_(True), 2, 2)
+    assert torch.equal(y, yr)
+    go = g(synth.normal("pool/go%s" % (shape,), tuple(y.shape)))
+    (gx,) = torch.autograd.grad(y, x, go)
+    xr = x.detach().clone().requires_grad_(True)
+    (gr,) = torch.autograd.grad(F.max_pool2d(xr, 2, 2), xr, go)
+    assert torch.equal(gx, gr)
