@@ -17,7 +17,7 @@ import torch.nn as nn
 from torch.nn.modules.utils import _pair
 
 from .... import _C
-from ..conv3x3 import conv3x3_infer, conv_raw
+from ..conv3x3 import conv3x3_infer, conv_bias_act, conv_raw
 
 
 def _shape(x, weight, stride, pad, dil, dg):
@@ -148,6 +148,9 @@ def conv_bias(conv, x):
     in-place epilogue and one channel-sum kernel."""
     if x.is_cuda and conv.bias is not None and torch.is_grad_enabled() and x.dtype == torch.float32 \
             and conv.groups == 1:
+        y = conv_bias_act(conv, x, False)               # bias in the convolution kernel's epilogue
+        if y is not None:
+            return y
         y = conv_raw(conv, x)
         if y.is_contiguous() and (y.shape[2] * y.shape[3]) % 4 == 0 and y.shape[0] * y.shape[1] <= 65535:
             return _ConvBias.apply(y, conv.bias)

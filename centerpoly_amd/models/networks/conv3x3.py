@@ -194,6 +194,49 @@ def grads(x, weight, go, want_x=True, want_w=True, min_k=1):
     return gx, gw
 
 
+class _ConvBiasActFn(torch.autograd.Function):
+    """Training: stride-1 convolution + bias (+ ReLU) with the bias / ReLU in the kernel's epilogue (no separate pass
+    over the output); backward: ReLU mask + bias gradient in one pass (cp_bias_relu_backward) or a channel sum of
+    grad_out (cp_channel_sum_accumulate), then the convolution's gradients."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, relu):
+        cout, cin = weight.shape[0], weight.shape[1]
+        y = _launch(x, _prepare(weight, cin, cout, False), bias, None, cout, relu, weight.shape[2] * weight.shape[3])
+        ctx.relu = relu
+        ctx.save_for_backward(x, weight, y if relu else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, go):
+        x, weight, y = ctx.saved_tensors
+        go = go.contiguous()
+        B, C, H, W = go.shape
+        L = _C.lib()
+        gb = torch.zeros(C, dtype=torch.float32, device=go.device)
+        if ctx.relu:
+            g = torch.empty_like(go)
+            _C.check(L.cp_bias_relu_backward(_C.ptr(y), _C.ptr(go), _C.ptr(g), _C.ptr(gb), B, C, H * W, _C.stream()),
+                     "cp_bias_relu_backward")
+        else:
+            g = go
+            _C.check(L.cp_channel_sum_accumulate(_C.ptr(go), _C.ptr(gb), B, C, H * W, _C.stream()),
+                     "cp_channel_sum_accumulate")
+        gx, gw = grads(x, weight, g, ctx.needs_input_grad[0], ctx.needs_input_grad[1], min_k=MIN_CIN)
+        return gx, gw, (gb if ctx.needs_input_grad[2] else None), None
+
+
+def conv_bias_act(conv, x, relu):
+    """conv(x) + bias (+ ReLU), differentiable, as ONE forward launch when the shape is the MFMA kernel's
+    (stride 1); None otherwise (the caller falls back to conv_raw + its separate epilogue)."""
+    if conv.bias is None or conv.stride != (1, 1) or not usable(conv, x):
+        return None
+    B, _, H, W = x.shape
+    if (H * W) % 4 != 0 or B * conv.out_channels > 65535:          # (limits of the backward's epilogue kernels)
+        return None
+    return _ConvBiasActFn.apply(x.contiguous(), conv.weight, conv.bias, bool(relu))
+
+
 def conv_raw(conv, x):
     """conv(x) WITHOUT its bias, differentiable: the MFMA kernel for its shapes, the library otherwise."""
     if usable(conv, x):

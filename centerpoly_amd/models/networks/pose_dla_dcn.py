@@ -227,6 +227,9 @@ def conv_bias_relu(conv, x):
     """conv (with bias) followed by ReLU: fused epilogue on a HIP device in training."""
     if (x.is_cuda and conv.bias is not None and x.dtype == torch.float32 and torch.is_grad_enabled()
             and conv.groups == 1):
+        y = conv3x3.conv_bias_act(conv, x, True)        # bias + ReLU in the convolution kernel's epilogue
+        if y is not None:
+            return y
         y = conv_raw(conv, x)
         if y.is_contiguous() and (y.shape[2] * y.shape[3]) % 4 == 0 and y.shape[0] * y.shape[1] <= 65535:
             return _BiasRelu.apply(y, conv.bias)
