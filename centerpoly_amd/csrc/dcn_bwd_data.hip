@@ -81,6 +81,7 @@ struct D2Args {
   const float* go;
   const f32x4* wp;           // permuted weights [chunk][slab][tap][ks4][lane] x 4 floats
   const float* wmax;         // max |W|
+  unsigned* cold_flag;       // set when any wave took the cold path (float atomics straight into grad_x)
   float* gx;                 // cold path only (may be null)
   float* slab;               // [B][tiles][Cin][RSZ]
   float* goff;               // slices == 1: final tensors; else partial sums [slice][B][27][HW]
@@ -255,6 +256,7 @@ __global__ __launch_bounds__(TH * 64, TH / 4) void dcn_bwd_data2_kernel(D2Args a
     }
   }
   const bool any_fallback = __builtin_amdgcn_ballot_w64(lane_fb) != 0ull;
+  if (WANT_GX && any_fallback && lane == 0) atomicOr(a.cold_flag, 1u);   // the reduce then adds onto grad_x
   const unsigned long long t_rec = CP_T();
   (void)t_rec;
 
@@ -655,8 +657,8 @@ __global__ __launch_bounds__(TH * 64, TH / 4) void dcn_bwd_data2_kernel(D2Args a
 // the diagonal ones.
 template <bool VEC>
 __global__ __launch_bounds__(256) void dcn_bwd_gx_reduce_kernel(const float* __restrict__ slab, float* __restrict__ gx,
-                                                                int BC, int Cin, int H, int W, int tpr, int tpc,
-                                                                int TH) {
+                                                                const unsigned* __restrict__ cold_flag, int BC, int Cin,
+                                                                int H, int W, int tpr, int tpc, int TH) {
   constexpr int V = VEC ? 4 : 1;
   const int xq = blockIdx.x * 64 + (threadIdx.x & 63);              // float4 (or pixel) index in the row
   const int x = xq * V;
@@ -689,13 +691,16 @@ __global__ __launch_bounds__(256) void dcn_bwd_gx_reduce_kernel(const float* __r
       }
     }
   }
+  // grad_x already holds something only if a wave gathered outside its region (float atomics of the cold path):
+  // otherwise it is overwritten and its 4 bytes per element are not read
+  const bool add = *cold_flag != 0u;
   float* o = gx + ((long long)bc * H + y) * W + x;
   if (VEC) {
-    float4 v = *reinterpret_cast<float4*>(o);
+    float4 v = add ? *reinterpret_cast<float4*>(o) : make_float4(0.f, 0.f, 0.f, 0.f);
     v.x += s[0]; v.y += s[1 % V]; v.z += s[2 % V]; v.w += s[3 % V];
     *reinterpret_cast<float4*>(o) = v;
   } else {
-    o[0] += s[0];
+    o[0] = (add ? o[0] : 0.f) + s[0];
   }
 }
 
@@ -827,7 +832,7 @@ int cp_dcn_bwd_data2(const cp_dcn_shape* s, const float* x, const float* offset,
   char* ws = (char*)workspace;
   unsigned* wmax_bits = (unsigned*)(ws + p.off_wmax);
   f32x4* wp = (f32x4*)(ws + p.off_wp);
-  (void)hipMemsetAsync(wmax_bits, 0, 4, st);
+  (void)hipMemsetAsync(wmax_bits, 0, 8, st);                 // max |W| and the cold-path flag
   const int total_f4 = p.chunks * p.NS * A_F4;
   if (d2_exact_f32())
     hipLaunchKernelGGL(dcn_bwd_wperm_kernel, dim3((total_f4 + 255) / 256), dim3(256), 0, st, weight, (float4*)wp,
@@ -837,7 +842,7 @@ int cp_dcn_bwd_data2(const cp_dcn_shape* s, const float* x, const float* offset,
                        wmax_bits, s->Cin, s->Cout, p.NS, total_f4);
   const int HW = s->H * s->W;
   D2Args a;
-  a.x = x; a.offset = offset; a.mask = mask; a.go = grad_out; a.wp = wp; a.wmax = (const float*)wmax_bits;
+  a.x = x; a.offset = offset; a.mask = mask; a.go = grad_out; a.wp = wp; a.wmax = (const float*)wmax_bits; a.cold_flag = wmax_bits + 1;
   a.gx = grad_x; a.slab = want_gx ? (float*)(ws + p.off_slab) : nullptr;
   a.offset_bstride = offset_bstride; a.mask_bstride = mask_bstride;
   a.B = s->B; a.Cin = s->Cin; a.H = s->H; a.W = s->W; a.Cout = s->Cout;
@@ -864,11 +869,11 @@ int cp_dcn_bwd_data2(const cp_dcn_shape* s, const float* x, const float* offset,
     const int per_row = vec ? s->W / 4 : s->W;
     const dim3 grid((per_row + 63) / 64, s->H, (s->B * s->Cin + 3) / 4);
     if (vec)
-      hipLaunchKernelGGL(dcn_bwd_gx_reduce_kernel<true>, grid, dim3(256), 0, st, a.slab, grad_x, s->B * s->Cin, s->Cin,
-                         s->H, s->W, p.tpr, p.tpc, p.TH);
+      hipLaunchKernelGGL(dcn_bwd_gx_reduce_kernel<true>, grid, dim3(256), 0, st, a.slab, grad_x, a.cold_flag,
+                         s->B * s->Cin, s->Cin, s->H, s->W, p.tpr, p.tpc, p.TH);
     else
-      hipLaunchKernelGGL(dcn_bwd_gx_reduce_kernel<false>, grid, dim3(256), 0, st, a.slab, grad_x, s->B * s->Cin, s->Cin,
-                         s->H, s->W, p.tpr, p.tpc, p.TH);
+      hipLaunchKernelGGL(dcn_bwd_gx_reduce_kernel<false>, grid, dim3(256), 0, st, a.slab, grad_x, a.cold_flag,
+                         s->B * s->Cin, s->Cin, s->H, s->W, p.tpr, p.tpc, p.TH);
   } else {
     if (p.NS == 1) d2_launch<64, false>(a, p, s->B, st);
     else if (p.NS == 2) d2_launch<128, false>(a, p, s->B, st);
