@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libcenterpoly_hip.so")
 CP_OK = 0
 REP = {"cartesian": 0, "polar": 1, "polar_fixed": 2}
 L1_PLAIN, L1_POLAR, L1_POLAR_FIXED, L1_RELU20, L1_SMOOTH = 0, 1, 2, 3, 4
-DCN_CONTRACTION = {"f32": 0, "bf16x3": 1}
+DCN_CONTRACTION = {"f32": 0, "bf16x3": 1, "bf16x3_region": 3}     # (+1 = "..._PREPARED": weights already in the workspace)
 
 
 class DcnShape(Structure):

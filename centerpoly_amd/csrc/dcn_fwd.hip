@@ -20,6 +20,7 @@
 // LDS rows are padded to an odd dword count so both the lane=pixel writes and the
 // lane=(row, k) fragment reads are bank-conflict free.
 #include "cp_common.h"
+#include "dcn_internal.h"
 #include <stdlib.h>
 
 namespace {
@@ -762,8 +763,25 @@ int launch_pipe(const DcnFwdArgs& a, hipStream_t st) {
   return cp_launch_status();
 }
 
-size_t wperm_bytes(int Cin, int Cout) {                    // 16-row tiles padded to whole groups of 8 (BN = 128)
+size_t wperm_bytes_gather(int Cin, int Cout) {             // 16-row tiles padded to whole groups of 8 (BN = 128)
   return (size_t)((Cout + 127) / 128 * 8) * ((Cin + 7) / 8) * 3 * 2 * 64 * 16;
+}
+
+// head of the workspace: room for the permuted weights of whichever split-bf16 kernel the plan picks
+size_t wperm_bytes(const cp_dcn_shape* s) {
+  size_t n = wperm_bytes_gather(s->Cin, s->Cout);
+  if (cp_dcn_region_supported(s)) {
+    const size_t r = cp_dcn_region_wperm_bytes(s);
+    if (r > n) n = r;
+  }
+  return cp_align_up(n, 256);
+}
+
+// The region kernel (dcn_fwd_region.hip) pays where its 8 x 32 pixel tiles x 64-channel blocks fill the chip; small
+// maps keep the gather kernels with their K split.
+bool region_pays(const cp_dcn_shape* s) {
+  const long long wgs = (long long)((s->H + 7) / 8) * ((s->W + 31) / 32) * ((s->Cout + 63) / 64) * s->B;
+  return wgs >= 256;
 }
 
 template <int BN, int WPS>
@@ -794,7 +812,7 @@ extern "C" size_t cp_dcn_v2_forward_workspace_bytes(const cp_dcn_shape* s) {
   const Plan p = make_plan(s->B, s->Cin, s->Cout, Ho * Wo);
   // [permuted weights of the split-bf16 contraction | K-split partial sums]
   const size_t part = p.splitk <= 1 ? 0 : (size_t)p.splitk * s->B * s->Cout * Ho * Wo * sizeof(float);
-  return wperm_bytes(s->Cin, s->Cout) + part;
+  return wperm_bytes(s) + part;
 }
 
 extern "C" int cp_dcn_v2_forward(const cp_dcn_shape* s, const float* x, const float* offset,
@@ -815,8 +833,21 @@ extern "C" int cp_dcn_v2_forward(const cp_dcn_shape* s, const float* x, const fl
   if (s->W < 2) return CP_EUNSUPPORTED;          // the x-pair gathers need two columns
   const Plan p = make_plan(s->B, s->Cin, s->Cout, Ho * Wo);
   if ((long long)s->B * p.splitk > 65535) return CP_EUNSUPPORTED;
-  const size_t wpb = wperm_bytes(s->Cin, s->Cout);
-  const bool bf = contraction == CP_DCN_BF16X3 || contraction == CP_DCN_BF16X3_PREPARED;
+  const size_t wpb = wperm_bytes(s);
+  const bool force_region = contraction == CP_DCN_BF16X3_REGION || contraction == CP_DCN_BF16X3_REGION_PREPARED;
+  const bool prepared = contraction == CP_DCN_BF16X3_PREPARED || contraction == CP_DCN_BF16X3_REGION_PREPARED;
+  const bool bf = contraction == CP_DCN_BF16X3 || contraction == CP_DCN_BF16X3_PREPARED || force_region;
+  if (force_region && !cp_dcn_region_supported(s)) return CP_EUNSUPPORTED;
+  if (bf && cp_dcn_region_supported(s) && (force_region || region_pays(s))) {
+    if (!workspace || workspace_bytes < cp_dcn_v2_forward_workspace_bytes(s)) return CP_EWORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    if (!prepared) {
+      const int rc = cp_dcn_region_prepare(s, weight, workspace, st);
+      if (rc != CP_OK) return rc;
+    }
+    return cp_dcn_region_forward(s, x, offset, offset_bstride, mask, mask_bstride, mask_is_logit, workspace, bias,
+                                 ep_scale, ep_shift, relu, out, st);
+  }
   if (p.splitk > 1 || bf) {
     if (!workspace || workspace_bytes < cp_dcn_v2_forward_workspace_bytes(s)) return CP_EWORKSPACE;
   }
@@ -838,9 +869,9 @@ extern "C" int cp_dcn_v2_forward(const cp_dcn_shape* s, const float* x, const fl
   CP_CHECK_ARG(contraction == CP_DCN_F32 || bf);
   if ((unsigned long long)s->Cout * s->Cin * 9ull * 4ull >= 0xE0000000ull) return CP_EUNSUPPORTED;
   if (bf && p.bn <= 128 && (p.c_per_split % 8) == 0) {
-    if (contraction == CP_DCN_BF16X3) {                     // (PREPARED: the workspace already holds them)
+    if (!prepared) {                                        // (PREPARED: the workspace already holds them)
       const int nchunk = (s->Cin + 7) / 8;
-      const int total = (int)(wpb / 16);
+      const int total = (int)(wperm_bytes_gather(s->Cin, s->Cout) / 16);
       hipLaunchKernelGGL(dcn_fwd_wperm_kernel, dim3((total + 255) / 256), dim3(256), 0, st, weight, (bf16x8*)workspace,
                          s->Cout, s->Cin, nchunk, total);
     }

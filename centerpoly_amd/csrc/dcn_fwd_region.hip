@@ -1,0 +1,432 @@
+// DCNv2 forward, region form (gfx950): the input tile of a block of output pixels is staged ONCE per 16-channel
+// chunk into LDS with coalesced row loads, the bilinear samples are read back from LDS by the lane that needs them
+// and go STRAIGHT into bf16 MFMA operand registers -- no per-lane global gathers, no column tile, no f32 MFMA.
+//
+// Replaces (together with dcn_fwd.hip) the native extension behind `from .DCNv2.dcn_v2 import DCN`
+// (reference: src/lib/models/networks/pose_dla_dcn.py:16, call site :354).
+//
+// Why: the gather kernels of dcn_fwd.hip are bound by the texture addresser (two 8-byte gathers per channel, tap and
+// pixel) and, on the 64-channel layers, by the f32 MFMA sharing the vector ALU with the sampling arithmetic.
+//
+//   * Workgroup = 4 waves = a tile of 8 rows x 32 columns of one image x 64 output channels.  Wave w owns rows
+//     2w, 2w + 1; a row of 32 pixels is the N side of v_mfma_f32_32x32x16_bf16, 32 output channels the M side,
+//     16 input channels of one tap the K side: lane (pixel = lane & 31, half = lane >> 5) supplies the 8 channels
+//     8 half .. 8 half + 7 of its pixel -- exactly the 8 values it samples.
+//   * Region: (8 + 8) x (32 + 8) input cells around the tile, channel-interleaved in groups of four
+//     ([group][row][col] float4), so a corner of 4 channels is ONE ds_read_b128 and the x neighbour is the next
+//     16 bytes.  Cells outside the image are staged as zeros (buffer loads past num_records), which is DCNv2's
+//     per-corner bounds rule.  The region origin follows the tile's sampling positions: a block-wide min / max of
+//     the integer corners picks the window, so a smooth offset field of any size costs nothing; samples that still
+//     fall outside (white-noise offsets beyond +-2 rows / +-3 columns) take a wave-uniformly skipped cold path with
+//     global gathers.  Two chunk buffers: the next chunk is staged (buffer loads -> ds_write_b128, spread over the
+//     taps) while the current one is sampled; one barrier per chunk.
+//   * Per (row, tap, chunk) step a lane reads 8 x 16 bytes, forms 8 bilinear values (fp32 fma chain), splits each
+//     into bf16 hi + lo and feeds 2 x 3 MFMAs (hi*hi + hi*lo + lo*hi, fp32 accumulate: ~2^-16 relative, an fp32
+//     emulation).  The weights come pre-split in A-fragment order (dcn_region_wperm_kernel) straight from global
+//     memory (L1 / L2 resident, 4 KB per tap and chunk, shared by both rows), one tap ahead.
+//   * Per-pixel sampling recipes (ly, lx, mask, region byte offset) of the wave's 2 x 9 (row, tap) pairs stay in
+//     registers for the whole K loop.
+// LDS: 2 x 40 KB = exactly half a CU's 160 KB, two workgroups per CU (8 waves, 256 registers each).
+#include "cp_common.h"
+#include "dcn_internal.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+
+constexpr int TH = 8, TW = 32;            // output tile
+constexpr int RH = 16, RW = 40;           // staged region
+constexpr int CELLS = RH * RW;            // 640
+constexpr int PLANE = CELLS * 16;         // bytes of one 4-channel group
+constexpr int CHB = 4 * PLANE;            // bytes of one 16-channel chunk buffer (40 960)
+constexpr int TAPS = 9;
+constexpr int ITEMS = CELLS * 4 / 256;    // float4 cells staged per thread and chunk (10)
+constexpr unsigned OOB = 0x80000000u;     // voffset past every num_records (< 2^31, also with the scalar offset added): the load returns 0
+static_assert(CELLS * 4 % 256 == 0, "staging items divide evenly");
+
+struct RegionArgs {
+  const float* x;
+  const float* offset;
+  const float* mask;
+  const bf16x8* wp;
+  const float* bias;
+  const float* ep_scale;
+  const float* ep_shift;
+  float* out;
+  long long offset_bstride, mask_bstride;
+  int B, Cin, H, W, Cout;
+  int mask_is_logit, relu;
+  int tiles_x, tiles_y;
+};
+
+// wp[(((cb * nchunk + chunk) * 9 + t) * 4 + ct * 2 + hl) * 64 + lane][j] =
+//     half hl of W[co = 64 cb + 32 ct + (lane & 31)][ci = 16 chunk + 8 (lane >> 5) + j][t]   (0 for co >= Cout)
+__global__ __launch_bounds__(256) void dcn_region_wperm_kernel(const float* __restrict__ w, bf16x8* __restrict__ wp,
+                                                               int Cout, int Cin, int nchunk, int total) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= total) return;
+  const int lane = e & 63;
+  int r = e >> 6;
+  const int hl = r & 1, ct = (r >> 1) & 1;
+  r >>= 2;
+  const int t = r % TAPS;
+  r /= TAPS;
+  const int chunk = r % nchunk, cb = r / nchunk;
+  const int co = cb * 64 + ct * 32 + (lane & 31);
+  bf16x8 o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int ci = chunk * 16 + 8 * (lane >> 5) + j;
+    const float v = (co < Cout && ci < Cin) ? w[((long long)co * Cin + ci) * TAPS + t] : 0.f;
+    const __bf16 h = (__bf16)v;
+    o[j] = hl ? (__bf16)(v - (float)h) : h;
+  }
+  wp[e] = o;
+}
+
+__device__ __forceinline__ unsigned pk_min(unsigned a, unsigned b) {
+  return __builtin_bit_cast(unsigned, __builtin_elementwise_min(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b)));
+}
+__device__ __forceinline__ unsigned pk_max(unsigned a, unsigned b) {
+  return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b)));
+}
+
+// fp32 pair -> bf16 hi pair + bf16 lo pair (v = hi + lo up to 2^-17 relative)
+__device__ __forceinline__ void split2(float v0, float v1, unsigned& hi, unsigned& lo) {
+  const bf16x2 h = __builtin_convertvector(f32x2{v0, v1}, bf16x2);
+  const unsigned hb = __builtin_bit_cast(unsigned, h);
+  const float h0 = __builtin_bit_cast(float, hb << 16), h1 = __builtin_bit_cast(float, hb & 0xffff0000u);
+  const bf16x2 l = __builtin_convertvector(f32x2{v0 - h0, v1 - h1}, bf16x2);
+  hi = hb;
+  lo = __builtin_bit_cast(unsigned, l);
+}
+
+// Value held by lane half 0 -> r0 in every lane, value held by lane half 1 -> r1 in every lane (one v_permlane32_swap:
+// lanes 32-63 of the first operand trade places with lanes 0-31 of the second).  The empty asm keeps hipcc (ROCm 7.2)
+// from folding the two results into one when they are bit-cast to float (it then stores r0 twice).
+__device__ __forceinline__ void bcast_rows(unsigned u, unsigned& r0, unsigned& r1) {
+  const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  r0 = r[0];
+  r1 = r[1];
+  asm("" : "+v"(r0), "+v"(r1));
+}
+
+__global__ __launch_bounds__(256, 2) void dcn_fwd_region_kernel(RegionArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int px = lane & 31, kg = lane >> 5;
+  const int H = a.H, W = a.W, HW = H * W;
+
+  // XCD-aware tile order: blocks b and b + 8 share an XCD (and its L2); give each XCD a contiguous band of tiles
+  const int ntile = a.tiles_x * a.tiles_y;
+  int tile = blockIdx.x;
+  if ((ntile & 7) == 0) tile = (tile & 7) * (ntile >> 3) + (tile >> 3);
+  const int ty = (tile / a.tiles_x) * TH, tx = (tile % a.tiles_x) * TW;
+  const int b = blockIdx.z, cb = blockIdx.y;
+  const int nchunk = a.Cin >> 4;
+  const unsigned plane_bytes = (unsigned)HW * 4u;
+
+  // Buffer descriptors span the whole tensor of the image; a channel plane rides in the scalar offset.  (Measured on
+  // gfx950: the range check is on voffset + soffset, so num_records must cover the planes; OOB = 2^31 fails it under
+  // either rule and the load returns 0.)
+  const __amdgpu_buffer_rsrc_t rs_off = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.offset + (long long)b * a.offset_bstride), 0, (int)(18u * plane_bytes), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_msk = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.mask + (long long)b * a.mask_bstride), 0, (int)(9u * plane_bytes), 0x00020000);
+  // x: voffset carries (group plane + pixel), soffset the chunk's channel plane
+  const float* xb = a.x + (long long)b * a.Cin * HW;
+  const __amdgpu_buffer_rsrc_t rs_x =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xb), 0, (int)((unsigned)a.Cin * plane_bytes), 0x00020000);
+
+  // ------------------------------------------------------------------ sampling recipes
+  // Lane half h computes and KEEPS the 9 recipes of row 2w + h of its pixel column (both halves of a lane pair need
+  // the recipe of the row being processed: it is broadcast per tap with one v_permlane32_swap per value, below):
+  //   u0 = (1 - ly) * mask, u1 = ly * mask, lx, region byte offset.   u0 = -0.0f marks a cold sample (weights 0).
+  float ru0[TAPS], ru1[TAPS], rlx[TAPS];
+  unsigned roff[TAPS];                    // first (y0 + 1) << 16 | (x0 + 1), later the region byte offset
+  unsigned bb_lo = 0xFFFFFFFFu, bb_hi = 0u;
+  {
+    const int y = ty + 2 * wid + kg, x = tx + px;
+    const bool ok = y < H && x < W;
+    const unsigned vo = ok ? (unsigned)(y * W + x) * 4u : OOB;
+    float oy[TAPS], ox[TAPS], ml[TAPS];
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t) {
+      oy[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_off, vo, (unsigned)(2 * t) * plane_bytes, 0));
+      ox[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_off, vo, (unsigned)(2 * t + 1) * plane_bytes, 0));
+      ml[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_msk, vo, (unsigned)t * plane_bytes, 0));
+    }
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t) {
+      const int ky = t / 3, kx = t - ky * 3;
+      float m = ml[t];
+      if (a.mask_is_logit) m = 1.f / (1.f + __expf(-m));
+      const float py = (float)(y - 1 + ky) + oy[t];
+      const float pxf = (float)(x - 1 + kx) + ox[t];
+      const bool inside = ok && py > -1.f && pxf > -1.f && py < (float)H && pxf < (float)W;
+      const float fy = floorf(py), fx = floorf(pxf);
+      const float ly = inside ? py - fy : 0.f;   // (!inside: weights exactly +0, whatever the offsets hold)
+      if (!inside) m = 0.f;
+      ru0[t] = (1.f - ly) * m;
+      ru1[t] = ly * m;
+      rlx[t] = inside ? pxf - fx : 0.f;
+      const unsigned pk = inside ? (((unsigned)((int)fy + 1)) << 16) | (unsigned)((int)fx + 1) : 0xFFFFFFFFu;
+      roff[t] = pk;
+      bb_lo = pk_min(bb_lo, pk);
+      bb_hi = pk_max(bb_hi, inside ? pk : 0u);
+    }
+  }
+  // block-wide bounding box of the integer corners -> region origin
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    bb_lo = pk_min(bb_lo, (unsigned)__shfl_xor((int)bb_lo, o, 64));
+    bb_hi = pk_max(bb_hi, (unsigned)__shfl_xor((int)bb_hi, o, 64));
+  }
+  unsigned* scratch = reinterpret_cast<unsigned*>(smem + 2 * CHB - 64);      // tail of buffer 1: free until chunk 0 runs
+  if (lane == 0) {
+    scratch[2 * wid] = bb_lo;
+    scratch[2 * wid + 1] = bb_hi;
+  }
+  __syncthreads();
+  int oy0, ox0;
+  {
+    unsigned lo = scratch[0], hi = scratch[1];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) {
+      lo = pk_min(lo, scratch[2 * w]);
+      hi = pk_max(hi, scratch[2 * w + 1]);
+    }
+    lo = __builtin_amdgcn_readfirstlane(lo);
+    hi = __builtin_amdgcn_readfirstlane(hi);
+    const int ymin = (int)(lo >> 16) - 1, ymax = (int)(hi >> 16) - 1;
+    const int xmin = (int)(lo & 0xffffu) - 1, xmax = (int)(hi & 0xffffu) - 1;
+    const int spany = ymax + 2 - ymin, spanx = xmax + 2 - xmin;             // rows / columns the corners touch
+    oy0 = (spany > 0 && spany <= RH) ? ymin - ((RH - spany) >> 1) : ty - 4;  // else: symmetric window, |dy| < 3
+    ox0 = (spanx > 0 && spanx <= RW) ? xmin - ((RW - spanx) >> 1) : tx - 4;  //                         |dx| < 3
+  }
+
+  // recipes -> region byte offsets; samples outside the window are flagged cold (u0 = -0.0f, weights zero)
+  unsigned long long coldany[TAPS];       // per wave and tap: low word = lanes of row 0, high word = row 1
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t) {
+    const unsigned pk = roff[t];
+    const int iy = (int)(pk >> 16) - 1 - oy0, ix = (int)(pk & 0xffffu) - 1 - ox0;
+    const bool live = pk != 0xFFFFFFFFu;
+    const bool warm = (unsigned)iy <= (unsigned)(RH - 2) && (unsigned)ix <= (unsigned)(RW - 2);
+    const bool cold = live && !warm;
+    roff[t] = (live && warm) ? (unsigned)(iy * RW + ix) * 16u : 0u;
+    if (cold) {
+      ru0[t] = -0.f;
+      ru1[t] = 0.f;
+    }
+    coldany[t] = __builtin_amdgcn_ballot_w64(cold);
+  }
+
+  // staging addresses: this thread's float4 cells e = tid + 256 i; cells i and i + 5 are the same pixel two channel
+  // groups (8 planes) apart, so five offsets serve the ten items (the 8 planes ride in the scalar offset)
+  unsigned svo[ITEMS / 2];
+#pragma unroll
+  for (int i = 0; i < ITEMS / 2; ++i) {
+    const int e = tid + 256 * i;
+    const int g = e / CELLS, cell = e - g * CELLS;
+    const int ry = cell / RW, rx = cell - ry * RW;
+    const int gy = oy0 + ry, gx = ox0 + rx;
+    const bool in = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+    svo[i] = in ? ((unsigned)(g * 4) * (unsigned)HW + (unsigned)(gy * W + gx)) * 4u : OOB;
+  }
+  auto stage_load = [&](int i, int c0, f32x4& v) __attribute__((always_inline)) {
+    const int up = i >= ITEMS / 2 ? 8 : 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      v[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_x, svo[i % (ITEMS / 2)],
+                                                                          (unsigned)(c0 + q + up) * plane_bytes, 0));
+  };
+  auto stage_store = [&](int i, unsigned bufbase, const f32x4& v) __attribute__((always_inline)) {
+    *reinterpret_cast<f32x4*>(smem + bufbase + (unsigned)(tid + 256 * i) * 16u) = v;
+  };
+
+  // prologue: chunk 0 -> buffer 0
+#pragma unroll
+  for (int i0 = 0; i0 < ITEMS; i0 += 5) {
+    f32x4 sv[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) stage_load(i0 + i, 0, sv[i]);
+#pragma unroll
+    for (int i = 0; i < 5; ++i) stage_store(i0 + i, 0u, sv[i]);
+  }
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int r = 0; r < 2; ++r)
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[r][ct][i] = 0.f;
+
+  const bf16x8* wq = a.wp + (long long)cb * nchunk * (TAPS * 4 * 64) + lane;
+  bf16x8 wf[4];
+#pragma unroll
+  for (int f = 0; f < 4; ++f) wf[f] = wq[f * 64];
+  __syncthreads();
+
+  // cold path: the flagged lane pair of (row r, tap t) rebuilds its sample from the offset tensor and gathers
+  auto cold_fix = [&](int r, int t, int cbase, float (&v)[8]) __attribute__((always_inline)) {
+    const int y = ty + 2 * wid + r, x = tx + px;
+    const unsigned vo = (unsigned)(y * W + x) * 4u;
+    const float oyv = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_off, vo, (unsigned)(2 * t) * plane_bytes, 0));
+    const float oxv = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_off, vo, (unsigned)(2 * t + 1) * plane_bytes, 0));
+    float m = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_msk, vo, (unsigned)t * plane_bytes, 0));
+    if (a.mask_is_logit) m = 1.f / (1.f + __expf(-m));
+    const int ky = t / 3, kx = t - ky * 3;
+    const float py = (float)(y - 1 + ky) + oyv, pxf = (float)(x - 1 + kx) + oxv;
+    const float fy = floorf(py), fx = floorf(pxf);
+    const int y0 = (int)fy, x0 = (int)fx;
+    const float ly = py - fy, lx = pxf - fx, hx = 1.f - lx;
+    const float u0 = (1.f - ly) * m, u1 = ly * m;
+    const bool y0ok = y0 >= 0, y1ok = y0 + 1 < H, x0ok = x0 >= 0, x1ok = x0 + 1 < W;
+    const float w00 = (y0ok && x0ok) ? u0 * hx : 0.f, w01 = (y0ok && x1ok) ? u0 * lx : 0.f;
+    const float w10 = (y1ok && x0ok) ? u1 * hx : 0.f, w11 = (y1ok && x1ok) ? u1 * lx : 0.f;
+    const int ya = max(y0, 0), yb = min(y0 + 1, H - 1), xa = max(x0, 0), xc = min(x0 + 1, W - 1);
+    const float* p = xb + (long long)cbase * HW;
+#pragma unroll
+    for (int j = 0; j < 8; ++j, p += HW)
+      v[j] = w00 * p[ya * W + xa] + w01 * p[ya * W + xc] + w10 * p[yb * W + xa] + w11 * p[yb * W + xc];
+  };
+
+  const unsigned kgoff = (unsigned)kg * (2u * PLANE);
+  for (int c = 0; c < nchunk; ++c) {
+    const unsigned cur = (unsigned)(c & 1) * CHB, nxt = CHB - cur;
+    const unsigned curk = cur + kgoff;
+    const bool more = c + 1 < nchunk;
+    const int cn = (c + 1) * 16;
+    f32x4 sv[2];
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t) {
+      // recipe of tap t for row 0 (x[0]) and row 1 (x[1]) in both lane halves
+      unsigned bu0[2], bu1[2], blx[2], bof[2];
+      bcast_rows(__builtin_bit_cast(unsigned, ru0[t]), bu0[0], bu0[1]);
+      bcast_rows(__builtin_bit_cast(unsigned, ru1[t]), bu1[0], bu1[1]);
+      bcast_rows(__builtin_bit_cast(unsigned, rlx[t]), blx[0], blx[1]);
+      bcast_rows(roff[t], bof[0], bof[1]);
+      const bf16x8* qn = wq + (long long)((t + 1 < TAPS) ? c * TAPS + t + 1 : (more ? (c + 1) * TAPS : c * TAPS)) * (4 * 64);
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const int s = t * 2 + r;
+        // staging of the next chunk, spread over the steps: item s is issued here and written one step later
+        if (more) {
+          if (s >= 1 && s < ITEMS + 1) stage_store(s - 1, nxt, sv[(s - 1) & 1]);
+          if (s < ITEMS) stage_load(s, cn, sv[s & 1]);
+        }
+        // ---- sample 8 channels of (row r, tap t) for this lane's pixel
+        const unsigned ad = bof[r] + curk;
+        const f32x4 a00 = *reinterpret_cast<const f32x4*>(smem + ad);
+        const f32x4 a01 = *reinterpret_cast<const f32x4*>(smem + ad + 16);
+        const f32x4 a10 = *reinterpret_cast<const f32x4*>(smem + ad + RW * 16);
+        const f32x4 a11 = *reinterpret_cast<const f32x4*>(smem + ad + RW * 16 + 16);
+        const f32x4 b00 = *reinterpret_cast<const f32x4*>(smem + ad + PLANE);
+        const f32x4 b01 = *reinterpret_cast<const f32x4*>(smem + ad + PLANE + 16);
+        const f32x4 b10 = *reinterpret_cast<const f32x4*>(smem + ad + PLANE + RW * 16);
+        const f32x4 b11 = *reinterpret_cast<const f32x4*>(smem + ad + PLANE + RW * 16 + 16);
+        const float u0 = __builtin_bit_cast(float, bu0[r]), u1 = __builtin_bit_cast(float, bu1[r]);
+        const float lx = __builtin_bit_cast(float, blx[r]), hx = 1.f - lx;
+        const float w00 = u0 * hx, w01 = u0 * lx, w10 = u1 * hx, w11 = u1 * lx;
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          v[j] = w00 * a00[j] + w01 * a01[j] + w10 * a10[j] + w11 * a11[j];
+          v[4 + j] = w00 * b00[j] + w01 * b01[j] + w10 * b10[j] + w11 * b11[j];
+        }
+        if (__builtin_expect((unsigned)(coldany[t] >> (32 * r)) != 0u, 0)) {
+          if (bu0[r] == 0x80000000u) cold_fix(r, t, c * 16 + kg * 8, v);
+        }
+        unsigned hi[4], lo[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) split2(v[2 * j], v[2 * j + 1], hi[j], lo[j]);
+        const bf16x8 bh = __builtin_bit_cast(bf16x8, hi), bl = __builtin_bit_cast(bf16x8, lo);
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+          acc[r][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[2 * ct], bh, acc[r][ct], 0, 0, 0);
+          acc[r][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[2 * ct], bl, acc[r][ct], 0, 0, 0);
+          acc[r][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[2 * ct + 1], bh, acc[r][ct], 0, 0, 0);
+          if (r == 1) {                     // last use of this tap's fragments: fetch the next tap's into the same registers
+            wf[2 * ct] = qn[(2 * ct) * 64];
+            wf[2 * ct + 1] = qn[(2 * ct + 1) * 64];
+          }
+        }
+      }
+    }
+    __syncthreads();                        // next chunk staged, this one no longer read
+  }
+
+  // ------------------------------------------------------------------ epilogue: D[co][pixel]
+  const int x = tx + px;
+  if (x >= W) return;
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int co = cb * 64 + ct * 32 + (i & 3) + 8 * (i >> 2) + 4 * kg;
+      if (co >= a.Cout) continue;
+      float sc = 1.f, sh = 0.f;
+      if (a.ep_scale) sc = a.ep_scale[co];
+      if (a.ep_shift) sh = a.ep_shift[co];
+      else if (a.bias) sh = a.bias[co];
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const int y = ty + 2 * wid + r;
+        if (y >= H) continue;
+        float o = acc[r][ct][i] * sc + sh;
+        if (a.relu) o = fmaxf(o, 0.f);
+        a.out[(((long long)b * a.Cout + co) * H + y) * W + x] = o;
+      }
+    }
+}
+
+}  // namespace
+
+bool cp_dcn_region_supported(const cp_dcn_shape* s) {
+  if (s->kh != 3 || s->kw != 3 || s->stride != 1 || s->pad != 1 || s->dil != 1 || s->deformable_groups != 1) return false;
+  if (s->Cin < 16 || (s->Cin & 15)) return false;
+  const long long HW = (long long)s->H * s->W;
+  if (s->H >= 65534 || s->W >= 65534) return false;
+  if (HW * 4 * 27 >= (1ll << 31) || (long long)s->Cin * HW * 4 >= (1ll << 31)) return false;
+  if (s->B > 65535 || (s->Cout + 63) / 64 > 65535) return false;
+  return true;
+}
+
+size_t cp_dcn_region_wperm_bytes(const cp_dcn_shape* s) {
+  return (size_t)((s->Cout + 63) / 64) * (s->Cin / 16) * TAPS * 4 * 64 * 16;
+}
+
+int cp_dcn_region_prepare(const cp_dcn_shape* s, const float* weight, void* wp, hipStream_t st) {
+  const int total = (int)(cp_dcn_region_wperm_bytes(s) / 16);
+  hipLaunchKernelGGL(dcn_region_wperm_kernel, dim3((total + 255) / 256), dim3(256), 0, st, weight, (bf16x8*)wp, s->Cout,
+                     s->Cin, s->Cin / 16, total);
+  return cp_launch_status();
+}
+
+int cp_dcn_region_forward(const cp_dcn_shape* s, const float* x, const float* offset, int64_t offset_bstride,
+                          const float* mask, int64_t mask_bstride, int32_t mask_is_logit, const void* wp,
+                          const float* bias, const float* ep_scale, const float* ep_shift, int32_t relu, float* out,
+                          hipStream_t st) {
+  RegionArgs a;
+  a.x = x; a.offset = offset; a.mask = mask; a.wp = (const bf16x8*)wp; a.bias = bias;
+  a.ep_scale = ep_scale; a.ep_shift = ep_shift; a.out = out;
+  a.offset_bstride = offset_bstride; a.mask_bstride = mask_bstride;
+  a.B = s->B; a.Cin = s->Cin; a.H = s->H; a.W = s->W; a.Cout = s->Cout;
+  a.mask_is_logit = mask_is_logit; a.relu = relu;
+  a.tiles_x = (s->W + TW - 1) / TW;
+  a.tiles_y = (s->H + TH - 1) / TH;
+  const int lds = 2 * CHB;
+  static const hipError_t attr = hipFuncSetAttribute((const void*)dcn_fwd_region_kernel,
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  (void)attr;
+  dim3 grid(a.tiles_x * a.tiles_y, (s->Cout + 63) / 64, s->B);
+  hipLaunchKernelGGL(dcn_fwd_region_kernel, grid, dim3(256), lds, st, a);
+  return cp_launch_status();
+}

@@ -1,0 +1,12 @@
+// Internal interface between the translation units of the DCNv2 forward (not part of the C ABI).
+#pragma once
+#include "cp_common.h"
+
+// region-sampling split-bf16 kernel (dcn_fwd_region.hip): 3x3, stride 1, pad 1, dilation 1, Cin % 16 == 0
+bool cp_dcn_region_supported(const cp_dcn_shape* s);
+size_t cp_dcn_region_wperm_bytes(const cp_dcn_shape* s);
+int cp_dcn_region_prepare(const cp_dcn_shape* s, const float* weight, void* wp, hipStream_t st);
+int cp_dcn_region_forward(const cp_dcn_shape* s, const float* x, const float* offset, int64_t offset_bstride,
+                          const float* mask, int64_t mask_bstride, int32_t mask_is_logit, const void* wp,
+                          const float* bias, const float* ep_scale, const float* ep_shift, int32_t relu, float* out,
+                          hipStream_t st);

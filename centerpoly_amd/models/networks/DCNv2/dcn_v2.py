@@ -45,11 +45,13 @@ def dcn_v2_forward_raw(x, om, weight, bias, stride=1, pad=1, dil=1, dg=1, ep_sca
     nws = L.cp_dcn_v2_forward_workspace_bytes(s)
     mode = _C.DCN_CONTRACTION[contraction]
     ws = None
-    if owner is not None and mode == 1:
-        key = (weight._version, tuple(x.shape), tuple(om.shape))
+    if owner is not None and mode in (1, 3):
+        # (data_ptr / device in the key: `module.to(device)` or a `.data` swap re-points the Parameter's storage without
+        # a version bump; a stale workspace would then hold another tensor's weights, possibly on another device)
+        key = (weight._version, weight.data_ptr(), str(weight.device), mode, tuple(x.shape), tuple(om.shape))
         cache = owner.__dict__.get("_dcn_fwd_ws")
         if cache is not None and cache[0] is weight and cache[1] == key:
-            ws, mode = cache[2], 2                       # CP_DCN_BF16X3_PREPARED
+            ws, mode = cache[2], mode + 1                # CP_DCN_BF16X3[_REGION]_PREPARED
         else:
             ws = _C.workspace(nws, x.device)
             owner.__dict__["_dcn_fwd_ws"] = (weight, key, ws)

@@ -67,9 +67,13 @@ enum {
   CP_DCN_BF16X3 = 1, /* split-bf16: a*b ~ ah*bh + ah*bl + al*bh on bf16 MFMA, fp32 accumulate;
                         ~2^-16 relative error.  The weights are split and permuted into the
                         head of `workspace` by a prologue launch of the call                  */
-  CP_DCN_BF16X3_PREPARED = 2 /* the same, and `workspace` still holds the permuted weights of an
-                        earlier CP_DCN_BF16X3 call with the same weight tensor (inference:
-                        one workspace per layer, prologue paid once)                          */
+  CP_DCN_BF16X3_PREPARED = 2, /* the same, and `workspace` still holds the permuted weights of an
+                        earlier CP_DCN_BF16X3 call with the same weight tensor and shape
+                        (inference: one workspace per layer, prologue paid once)              */
+  CP_DCN_BF16X3_REGION = 3, /* CP_DCN_BF16X3 on the LDS-region kernel whatever the map size (the
+                        library otherwise picks it only where its tiles fill the chip);
+                        CP_EUNSUPPORTED unless 3x3, stride 1, pad 1, dilation 1, Cin % 16 == 0 */
+  CP_DCN_BF16X3_REGION_PREPARED = 4 /* ... with the weights already in `workspace`            */
 };
 
 /* regression flavour for cp_gather_l1_* */

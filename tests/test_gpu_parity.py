@@ -392,6 +392,27 @@ def test_dcn_forward_split_bf16_contraction(shape):
     np.testing.assert_allclose(out.numpy(), ref.numpy(), rtol=1e-3, atol=1e-4 * scale)
 
 
+REGION_SHAPES = [(1, 64, 64, 32, 64), (2, 128, 64, 24, 40), (1, 256, 128, 16, 32), (1, 16, 64, 40, 64), (2, 32, 40, 13, 19),
+                 (1, 64, 128, 6, 192), (1, 16, 20, 9, 7), (1, 48, 300, 7, 2), (3, 16, 64, 8, 32), (1, 32, 64, 70, 33)]
+
+
+@pytest.mark.parametrize("scale", [0.2, 1.0, 2.0, 6.0])
+@pytest.mark.parametrize("shape", REGION_SHAPES, ids=lambda s: "x".join(map(str, s)))
+def test_dcn_forward_region_kernel(shape, scale):
+    """The LDS-region kernel (dcn_fwd_region.hip; what "bf16x3" runs on the large maps), forced here on small and
+    ragged maps: tiles cut by the image edge, Cout off the 64-channel block, offsets from inside the staged window
+    (scale 0.2) to mostly outside it (scale 6: the cold gather path carries most samples)."""
+    from centerpoly_amd.models.networks.DCNv2.dcn_v2 import dcn_v2_forward_raw
+    B, Cin, Cout, H, W = shape
+    x, om, w, b = _dcn_inputs("region%dx%d" % (Cin, Cout), *shape, offset_scale=scale)
+    ref = _dcn_ref(x, om, w, b)
+    out = dcn_v2_forward_raw(g(x), g(om), g(w), g(b), contraction="bf16x3_region").cpu()
+    s_ = ref.abs().max().item()
+    err = (out - ref).abs().max().item() / s_
+    assert err < 1e-4, err
+    np.testing.assert_allclose(out.numpy(), ref.numpy(), rtol=1e-3, atol=1e-4 * s_)
+
+
 def test_dcn_large_offsets_and_borders():
     """Offsets that throw samples far outside the image (zero contribution) and exactly
     onto integer / border positions."""
