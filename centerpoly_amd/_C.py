@@ -44,6 +44,7 @@ _SIGNATURES = {
     "cp_strerror": (c_char_p, [c_int32]),
     "cp_build_arch": (c_char_p, []),
     "cp_dcn_v2_forward_workspace_bytes": (c_size_t, [POINTER(DcnShape)]),
+    "cp_dcn_v2_forward_kernel": (c_int32, [POINTER(DcnShape), c_int32]),
     "cp_dcn_v2_forward": (c_int32, [POINTER(DcnShape), _P, _P, c_int64, _P, c_int64, c_int32, _P, _P,
                                     _P, _P, c_int32, c_int32, _P, _P, c_size_t, _P]),
     "cp_dcn_v2_backward_workspace_bytes": (c_size_t, [POINTER(DcnShape)]),

@@ -781,7 +781,7 @@ size_t wperm_bytes(const cp_dcn_shape* s) {
 // maps keep the gather kernels with their K split.
 bool region_pays(const cp_dcn_shape* s) {
   const long long wgs = (long long)((s->H + 7) / 8) * ((s->W + 31) / 32) * ((s->Cout + 63) / 64) * s->B;
-  return wgs >= 256;
+  return wgs >= 128;
 }
 
 template <int BN, int WPS>
@@ -813,6 +813,15 @@ extern "C" size_t cp_dcn_v2_forward_workspace_bytes(const cp_dcn_shape* s) {
   // [permuted weights of the split-bf16 contraction | K-split partial sums]
   const size_t part = p.splitk <= 1 ? 0 : (size_t)p.splitk * s->B * s->Cout * Ho * Wo * sizeof(float);
   return wperm_bytes(s) + part;
+}
+
+extern "C" int cp_dcn_v2_forward_kernel(const cp_dcn_shape* s, int32_t contraction) {
+  if (!s) return CP_EINVAL;
+  if (contraction == CP_DCN_F32) return 0;
+  const bool force = contraction == CP_DCN_BF16X3_REGION || contraction == CP_DCN_BF16X3_REGION_PREPARED;
+  if (contraction != CP_DCN_BF16X3 && contraction != CP_DCN_BF16X3_PREPARED && !force) return CP_EINVAL;
+  if (cp_dcn_region_supported(s) && (force || region_pays(s))) return 2;
+  return force ? CP_EUNSUPPORTED : 1;
 }
 
 extern "C" int cp_dcn_v2_forward(const cp_dcn_shape* s, const float* x, const float* offset,

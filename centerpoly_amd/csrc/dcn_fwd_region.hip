@@ -45,6 +45,19 @@ constexpr int PLANE = CELLS * 16;         // bytes of one 4-channel group
 constexpr int CHB = 4 * PLANE;            // bytes of one 16-channel chunk buffer (40 960)
 constexpr int TAPS = 9;
 constexpr int ITEMS = CELLS * 4 / 256;    // float4 cells staged per thread and chunk (10)
+// timing-only ablation builds (make libcp_rabl_<mask>.so, tools/probe_region_ablate.py; results are wrong, never shipped):
+// 1 no weight re-loads, 2 no staging of later chunks, 4 no LDS sample reads, 8 no MFMA, 16 no bilinear / split arithmetic
+#ifndef CP_RABL
+#define CP_RABL 0
+#endif
+constexpr int RABL = CP_RABL;
+// diagnostic build (make libcp_rstamp.so, tools/probe_region_stamp.py): wave 0 of every workgroup overwrites 8 floats of
+// out[] with s_memtime deltas of its phases (the results are destroyed; never shipped)
+#ifdef CP_RSTAMP
+#define RSTAMP(i) do { stamp[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define RSTAMP(i) do { } while (0)
+#endif
 constexpr unsigned OOB = 0x80000000u;     // voffset past every num_records (< 2^31, also with the scalar offset added): the load returns 0
 static_assert(CELLS * 4 % 256 == 0, "staging items divide evenly");
 
@@ -121,6 +134,11 @@ __global__ __launch_bounds__(256, 2) void dcn_fwd_region_kernel(RegionArgs a) {
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int px = lane & 31, kg = lane >> 5;
   const int H = a.H, W = a.W, HW = H * W;
+#ifdef CP_RSTAMP
+  unsigned long long stamp[8];
+  const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
+  RSTAMP(0);
 
   // XCD-aware tile order: blocks b and b + 8 share an XCD (and its L2); give each XCD a contiguous band of tiles
   const int ntile = a.tiles_x * a.tiles_y;
@@ -181,6 +199,7 @@ __global__ __launch_bounds__(256, 2) void dcn_fwd_region_kernel(RegionArgs a) {
       bb_hi = pk_max(bb_hi, inside ? pk : 0u);
     }
   }
+  RSTAMP(1);
   // block-wide bounding box of the integer corners -> region origin
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
@@ -250,6 +269,7 @@ __global__ __launch_bounds__(256, 2) void dcn_fwd_region_kernel(RegionArgs a) {
     *reinterpret_cast<f32x4*>(smem + bufbase + (unsigned)(tid + 256 * i) * 16u) = v;
   };
 
+  RSTAMP(2);
   // prologue: chunk 0 -> buffer 0
 #pragma unroll
   for (int i0 = 0; i0 < ITEMS; i0 += 5) {
@@ -273,6 +293,7 @@ __global__ __launch_bounds__(256, 2) void dcn_fwd_region_kernel(RegionArgs a) {
 #pragma unroll
   for (int f = 0; f < 4; ++f) wf[f] = wq[f * 64];
   __syncthreads();
+  RSTAMP(3);
 
   // cold path: the flagged lane pair of (row r, tap t) rebuilds its sample from the offset tensor and gathers
   auto cold_fix = [&](int r, int t, int cbase, float (&v)[8]) __attribute__((always_inline)) {
@@ -304,87 +325,152 @@ __global__ __launch_bounds__(256, 2) void dcn_fwd_region_kernel(RegionArgs a) {
     const unsigned curk = cur + kgoff;
     const bool more = c + 1 < nchunk;
     const int cn = (c + 1) * 16;
-    f32x4 sv[2];
+    f32x4 sv[3];
 #pragma unroll
     for (int t = 0; t < TAPS; ++t) {
+      // weights of the next tap (or of tap 0 of the next chunk), a whole tap ahead of their first use
+      bf16x8 wn[4];
+      if (!(RABL & 1)) {
+        const bf16x8* qn = wq + (long long)((t + 1 < TAPS) ? c * TAPS + t + 1 : (more ? (c + 1) * TAPS : c * TAPS)) * (4 * 64);
+#pragma unroll
+        for (int f = 0; f < 4; ++f) wn[f] = qn[f * 64];
+      }
       // recipe of tap t for row 0 (x[0]) and row 1 (x[1]) in both lane halves
       unsigned bu0[2], bu1[2], blx[2], bof[2];
       bcast_rows(__builtin_bit_cast(unsigned, ru0[t]), bu0[0], bu0[1]);
       bcast_rows(__builtin_bit_cast(unsigned, ru1[t]), bu1[0], bu1[1]);
       bcast_rows(__builtin_bit_cast(unsigned, rlx[t]), blx[0], blx[1]);
       bcast_rows(roff[t], bof[0], bof[1]);
-      const bf16x8* qn = wq + (long long)((t + 1 < TAPS) ? c * TAPS + t + 1 : (more ? (c + 1) * TAPS : c * TAPS)) * (4 * 64);
 #pragma unroll
       for (int r = 0; r < 2; ++r) {
         const int s = t * 2 + r;
-        // staging of the next chunk, spread over the steps: item s is issued here and written one step later
-        if (more) {
-          if (s >= 1 && s < ITEMS + 1) stage_store(s - 1, nxt, sv[(s - 1) & 1]);
-          if (s < ITEMS) stage_load(s, cn, sv[s & 1]);
+        // staging of the next chunk, spread over the steps: item s is issued here and written two steps later
+        if (more && !(RABL & 2)) {
+          if (s >= 2 && s < ITEMS + 2) stage_store(s - 2, nxt, sv[(s - 2) % 3]);
+          if (s < ITEMS) stage_load(s, cn, sv[s % 3]);
         }
         // ---- sample 8 channels of (row r, tap t) for this lane's pixel
         const unsigned ad = bof[r] + curk;
-        const f32x4 a00 = *reinterpret_cast<const f32x4*>(smem + ad);
-        const f32x4 a01 = *reinterpret_cast<const f32x4*>(smem + ad + 16);
-        const f32x4 a10 = *reinterpret_cast<const f32x4*>(smem + ad + RW * 16);
-        const f32x4 a11 = *reinterpret_cast<const f32x4*>(smem + ad + RW * 16 + 16);
-        const f32x4 b00 = *reinterpret_cast<const f32x4*>(smem + ad + PLANE);
-        const f32x4 b01 = *reinterpret_cast<const f32x4*>(smem + ad + PLANE + 16);
-        const f32x4 b10 = *reinterpret_cast<const f32x4*>(smem + ad + PLANE + RW * 16);
-        const f32x4 b11 = *reinterpret_cast<const f32x4*>(smem + ad + PLANE + RW * 16 + 16);
+        f32x4 a00, a01, a10, a11, b00, b01, b10, b11;
+        if (RABL & 4) {
+          const float z = __builtin_bit_cast(float, ad);
+          a00 = a01 = a10 = a11 = f32x4{z, z, z, z};
+          b00 = b01 = b10 = b11 = f32x4{z, z, z, z};
+        } else {
+          a00 = *reinterpret_cast<const f32x4*>(smem + ad);
+          a01 = *reinterpret_cast<const f32x4*>(smem + ad + 16);
+          a10 = *reinterpret_cast<const f32x4*>(smem + ad + RW * 16);
+          a11 = *reinterpret_cast<const f32x4*>(smem + ad + RW * 16 + 16);
+          b00 = *reinterpret_cast<const f32x4*>(smem + ad + PLANE);
+          b01 = *reinterpret_cast<const f32x4*>(smem + ad + PLANE + 16);
+          b10 = *reinterpret_cast<const f32x4*>(smem + ad + PLANE + RW * 16);
+          b11 = *reinterpret_cast<const f32x4*>(smem + ad + PLANE + RW * 16 + 16);
+        }
         const float u0 = __builtin_bit_cast(float, bu0[r]), u1 = __builtin_bit_cast(float, bu1[r]);
         const float lx = __builtin_bit_cast(float, blx[r]), hx = 1.f - lx;
         const float w00 = u0 * hx, w01 = u0 * lx, w10 = u1 * hx, w11 = u1 * lx;
         float v[8];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          v[j] = w00 * a00[j] + w01 * a01[j] + w10 * a10[j] + w11 * a11[j];
-          v[4 + j] = w00 * b00[j] + w01 * b01[j] + w10 * b10[j] + w11 * b11[j];
+          if (RABL & 16) {
+            v[j] = a00[j] + w00;
+            v[4 + j] = b00[j] + w11;
+            asm volatile("" ::"v"(a01[j]), "v"(a10[j]), "v"(a11[j]), "v"(b01[j]), "v"(b10[j]), "v"(b11[j]), "v"(w01), "v"(w10));
+          } else {
+            v[j] = w00 * a00[j] + w01 * a01[j] + w10 * a10[j] + w11 * a11[j];
+            v[4 + j] = w00 * b00[j] + w01 * b01[j] + w10 * b10[j] + w11 * b11[j];
+          }
         }
         if (__builtin_expect((unsigned)(coldany[t] >> (32 * r)) != 0u, 0)) {
           if (bu0[r] == 0x80000000u) cold_fix(r, t, c * 16 + kg * 8, v);
         }
         unsigned hi[4], lo[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) split2(v[2 * j], v[2 * j + 1], hi[j], lo[j]);
+        for (int j = 0; j < 4; ++j) {
+          if (RABL & 16) {
+            hi[j] = __builtin_bit_cast(unsigned, v[2 * j]);
+            lo[j] = __builtin_bit_cast(unsigned, v[2 * j + 1]);
+          } else {
+            split2(v[2 * j], v[2 * j + 1], hi[j], lo[j]);
+          }
+        }
         const bf16x8 bh = __builtin_bit_cast(bf16x8, hi), bl = __builtin_bit_cast(bf16x8, lo);
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct) {
-          acc[r][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[2 * ct], bh, acc[r][ct], 0, 0, 0);
-          acc[r][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[2 * ct], bl, acc[r][ct], 0, 0, 0);
-          acc[r][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[2 * ct + 1], bh, acc[r][ct], 0, 0, 0);
-          if (r == 1) {                     // last use of this tap's fragments: fetch the next tap's into the same registers
-            wf[2 * ct] = qn[(2 * ct) * 64];
-            wf[2 * ct + 1] = qn[(2 * ct + 1) * 64];
+          if (RABL & 8) {
+            asm volatile("" ::"v"(bh), "v"(bl), "v"(wf[2 * ct]), "v"(wf[2 * ct + 1]));
+          } else {
+            acc[r][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[2 * ct], bh, acc[r][ct], 0, 0, 0);
+            acc[r][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[2 * ct], bl, acc[r][ct], 0, 0, 0);
+            acc[r][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[2 * ct + 1], bh, acc[r][ct], 0, 0, 0);
           }
         }
+      }
+      if (!(RABL & 1)) {
+#pragma unroll
+        for (int f = 0; f < 4; ++f) wf[f] = wn[f];
       }
     }
     __syncthreads();                        // next chunk staged, this one no longer read
   }
 
+  RSTAMP(4);
   // ------------------------------------------------------------------ epilogue: D[co][pixel]
-  const int x = tx + px;
-  if (x >= W) return;
+  // Accumulator layout: lane = pixel column (+ 4 channels per lane half), registers = channels.  Through LDS (the
+  // region buffers are free now; 16 KB per wave, [channel][row][32 px]) so that a lane stores 16 bytes: a quarter
+  // of the store instructions of the direct form, whose issue bounded the kernel's tail.
+  {
+    float* ot = reinterpret_cast<float*>(smem) + wid * (64 * 2 * 32);
 #pragma unroll
-  for (int ct = 0; ct < 2; ++ct)
+    for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int co = cb * 64 + ct * 32 + (i & 3) + 8 * (i >> 2) + 4 * kg;
-      if (co >= a.Cout) continue;
-      float sc = 1.f, sh = 0.f;
-      if (a.ep_scale) sc = a.ep_scale[co];
-      if (a.ep_shift) sh = a.ep_shift[co];
-      else if (a.bias) sh = a.bias[co];
+      for (int i = 0; i < 16; ++i) {
+        const int col = ct * 32 + (i & 3) + 8 * (i >> 2) + 4 * kg;
+        const int co = cb * 64 + col;
+        float sc = 1.f, sh = 0.f;
+        if (co < a.Cout) {
+          if (a.ep_scale) sc = a.ep_scale[co];
+          if (a.ep_shift) sh = a.ep_shift[co];
+          else if (a.bias) sh = a.bias[co];
+        }
 #pragma unroll
-      for (int r = 0; r < 2; ++r) {
-        const int y = ty + 2 * wid + r;
-        if (y >= H) continue;
-        float o = acc[r][ct][i] * sc + sh;
-        if (a.relu) o = fmaxf(o, 0.f);
-        a.out[(((long long)b * a.Cout + co) * H + y) * W + x] = o;
+        for (int r = 0; r < 2; ++r) {
+          float o = acc[r][ct][i] * sc + sh;
+          if (a.relu) o = fmaxf(o, 0.f);
+          ot[(col * 2 + r) * 32 + px] = o;
+        }
+      }
+    __syncthreads();
+    const bool wide = (W & 3) == 0 && (reinterpret_cast<unsigned long long>(a.out) & 15ull) == 0;
+#pragma unroll 4
+    for (int it = 0; it < 16; ++it) {
+      const int row = it * 8 + (lane >> 3);                  // (channel, tile row) pair: col * 2 + r
+      const int col = row >> 1, r = row & 1, x4 = tx + (lane & 7) * 4;
+      const int co = cb * 64 + col, y = ty + 2 * wid + r;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(ot + row * 32 + (lane & 7) * 4);
+      if (co >= a.Cout || y >= H || x4 >= W) continue;
+      float* dst = a.out + (((long long)b * a.Cout + co) * H + y) * W + x4;
+      if (wide) {
+        *reinterpret_cast<f32x4*>(dst) = v;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (x4 + j < W) dst[j] = v[j];
       }
     }
+  }
+#ifdef CP_RSTAMP
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  RSTAMP(5);
+  const unsigned long long rt1 = __builtin_amdgcn_s_memrealtime();
+  if (tid == 0) {
+    float* o = a.out + ((long long)b * gridDim.x + blockIdx.x) * 8;
+    for (int i = 0; i < 5; ++i) o[i] = (float)(stamp[i + 1] - stamp[i]);
+    o[5] = (float)(rt1 - rt0);          // 100 MHz ticks
+    o[6] = (float)(stamp[0] & 0xffffff);
+    o[7] = 0.f;
+  }
+#endif
 }
 
 }  // namespace

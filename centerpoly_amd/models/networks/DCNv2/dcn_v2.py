@@ -28,6 +28,21 @@ def _shape(x, weight, stride, pad, dil, dg):
     return s
 
 
+_AUTO = {}
+
+
+def auto_contraction(s):
+    """"auto": split-bf16 wherever the library runs its LDS-region kernel (the large maps, any channel count) and for the
+    layers with more than 64 output channels (gather kernel bound by the f32 matrix pipe); exact f32 for the rest
+    (small 64-channel maps: bound by their gathers, three waves per SIMD only in the f32 kernel)."""
+    key = (s.B, s.Cin, s.H, s.W, s.Cout, s.kh, s.kw, s.stride, s.pad, s.dil, s.deformable_groups)
+    c = _AUTO.get(key)
+    if c is None:
+        region = _C.lib().cp_dcn_v2_forward_kernel(s, _C.DCN_CONTRACTION["bf16x3"]) == 2
+        c = _AUTO[key] = "bf16x3" if (region or s.Cout > 64) else "f32"
+    return c
+
+
 def dcn_v2_forward_raw(x, om, weight, bias, stride=1, pad=1, dil=1, dg=1, ep_scale=None,
                        ep_shift=None, relu=False, contraction="f32", owner=None):
     """Forward on the raw offset/mask tensor `om` [B, 3*kh*kw, Ho, Wo] (mask as logits).
@@ -43,6 +58,8 @@ def dcn_v2_forward_raw(x, om, weight, bias, stride=1, pad=1, dil=1, dg=1, ep_sca
     bs = 3 * K * Ho * Wo
     mask_ptr = _C.c_void_p(om.data_ptr() + 4 * 2 * K * Ho * Wo)
     nws = L.cp_dcn_v2_forward_workspace_bytes(s)
+    if contraction == "auto":
+        contraction = auto_contraction(s)
     mode = _C.DCN_CONTRACTION[contraction]
     ws = None
     if owner is not None and mode in (1, 3):
@@ -78,9 +95,7 @@ class _DCNv2Function(torch.autograd.Function):
         ctx.cfg = (stride, pad, dil, dg)
         ctx.save_for_backward(x, om, weight)
         ctx.has_bias = bias is not None
-        # (as prepare_inference's "auto": split-bf16 for the layers bound by the f32 matrix pipe)
-        wide = weight.shape[0] > 64 and os.environ.get("CP_DCN_FWD_F32", "0") != "1"
-        return dcn_v2_forward_raw(x, om, weight, bias, stride, pad, dil, dg, contraction="bf16x3" if wide else "f32")
+        return dcn_v2_forward_raw(x, om, weight, bias, stride, pad, dil, dg, contraction=DCN.train_contraction)
 
     @staticmethod
     def backward(ctx, grad_out):
@@ -164,6 +179,9 @@ class DCN(nn.Module):
     """DCN(in_channels, out_channels, kernel_size, stride, padding, dilation=1,
     deformable_groups=1): forward(x[B,Cin,H,W]) -> [B,Cout,Ho,Wo]."""
 
+    # contraction of the TRAINING forward ("auto" | "f32" | "bf16x3"), a class-wide option (opt.dcn_contraction)
+    train_contraction = "auto"
+
     def __init__(self, in_channels, out_channels, kernel_size, stride, padding, dilation=1,
                  deformable_groups=1):
         super(DCN, self).__init__()
@@ -206,4 +224,4 @@ class DCN(nn.Module):
             om = cm(x)
         return dcn_v2_forward_raw(x.contiguous(), om.contiguous(), self.weight, None, self.stride,
                                   self.padding, self.dilation, self.deformable_groups, ep_scale,
-                                  ep_shift, relu, getattr(self, "contraction", "f32"), owner=self)
+                                  ep_shift, relu, getattr(self, "contraction", "auto"), owner=self)

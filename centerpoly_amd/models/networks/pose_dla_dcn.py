@@ -692,17 +692,15 @@ class DLASeg(nn.Module):
         """Fold every BatchNorm into its convolution / DCN epilogue and concatenate the heads'
         first 3x3 convolutions into one (call after loading weights, in eval mode).  Undone by
         train().  dcn_contraction: "f32" (exact fp32 MFMA), "bf16x3" (split-bf16 emulation,
-        ~2^-16 relative error) or "auto": bf16x3 for the DCN layers with more than 64 output
-        channels -- the ones bound by the f32 matrix pipe, 20 % faster in split-bf16 -- and f32
-        for the 64-channel ones, which are bound by their gathers and keep three waves per SIMD
-        in the f32 kernel."""
+        ~2^-16 relative error) or "auto" (DCNv2/dcn_v2.py::auto_contraction, decided per layer and map size at
+        the call: bf16x3 wherever the library runs its LDS-region kernel and for the layers with more than 64
+        output channels, f32 for the small 64-channel maps)."""
         self.eval()
         for m in self.modules():
             if hasattr(m, "fold"):
                 m.fold()
             if isinstance(m, DCN):
-                m.contraction = dcn_contraction if dcn_contraction != "auto" else \
-                    ("bf16x3" if m.out_channels > 64 else "f32")
+                m.contraction = dcn_contraction
         self._heads_cat = None
         fcs = [getattr(self, h) for h in self.heads]
         if all(isinstance(fc, nn.Sequential) and len(fc) == 3 for fc in fcs):

@@ -116,6 +116,10 @@ typedef struct cp_dcn_shape {
 } cp_dcn_shape;
 
 size_t cp_dcn_v2_forward_workspace_bytes(const cp_dcn_shape* s);
+/* Which kernel cp_dcn_v2_forward runs for this shape and contraction: 0 = gather kernel, exact fp32 MFMA;
+ * 1 = gather kernel, split-bf16; 2 = LDS-region kernel, split-bf16 (dcn_fwd_region.hip: the maps whose 8 x 32 pixel
+ * tiles fill the chip).  Lets a caller choose between CP_DCN_F32 and CP_DCN_BF16X3 per layer; negative = CP_E*. */
+int cp_dcn_v2_forward_kernel(const cp_dcn_shape* s, int32_t contraction);
 int cp_dcn_v2_forward(const cp_dcn_shape* s, const float* x, const float* offset,
                       int64_t offset_bstride, const float* mask, int64_t mask_bstride,
                       int32_t mask_is_logit, const float* weight, const float* bias,
