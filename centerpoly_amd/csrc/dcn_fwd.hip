@@ -781,7 +781,7 @@ size_t wperm_bytes(const cp_dcn_shape* s) {
 // maps keep the gather kernels with their K split.
 bool region_pays(const cp_dcn_shape* s) {
   const long long wgs = (long long)((s->H + 7) / 8) * ((s->W + 31) / 32) * ((s->Cout + 63) / 64) * s->B;
-  return wgs >= 128;
+  return wgs >= 256 || (wgs >= 128 && s->Cin <= 128);       // (deep, small maps: the gather kernels' K split fills the chip better)
 }
 
 template <int BN, int WPS>

@@ -37,6 +37,7 @@ typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int TH = 8, TW = 32;            // output tile
 constexpr int RH = 16, RW = 40;           // staged region
@@ -183,7 +184,7 @@ __global__ __launch_bounds__(256, 2) void dcn_fwd_region_kernel(RegionArgs a) {
     for (int t = 0; t < TAPS; ++t) {
       const int ky = t / 3, kx = t - ky * 3;
       float m = ml[t];
-      if (a.mask_is_logit) m = 1.f / (1.f + __expf(-m));
+      if (a.mask_is_logit) m = __builtin_amdgcn_rcpf(1.f + __expf(-m));      // (v_rcp_f32: 1 ulp)
       const float py = (float)(y - 1 + ky) + oy[t];
       const float pxf = (float)(x - 1 + kx) + ox[t];
       const bool inside = ok && py > -1.f && pxf > -1.f && py < (float)H && pxf < (float)W;
@@ -421,38 +422,50 @@ __global__ __launch_bounds__(256, 2) void dcn_fwd_region_kernel(RegionArgs a) {
   // of the store instructions of the direct form, whose issue bounded the kernel's tail.
   {
     float* ot = reinterpret_cast<float*>(smem) + wid * (64 * 2 * 32);
+    // per-channel epilogue constants: this lane's channels are 64 cb + 4 kg + a compile-time constant, so the loads
+    // are buffer loads with one per-lane offset and immediates (channels past Cout read 0)
+    const unsigned cbase = (unsigned)(cb * 64 + 4 * kg) * 4u;
+    const unsigned cbytes = (unsigned)a.Cout * 4u;
+    const float* shp = a.ep_shift ? a.ep_shift : a.bias;
+    const __amdgpu_buffer_rsrc_t rs_sc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.ep_scale), 0, a.ep_scale ? (int)cbytes : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_sh = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(shp), 0, shp ? (int)cbytes : 0, 0x00020000);
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        const int col = ct * 32 + (i & 3) + 8 * (i >> 2) + 4 * kg;
-        const int co = cb * 64 + col;
-        float sc = 1.f, sh = 0.f;
-        if (co < a.Cout) {
-          if (a.ep_scale) sc = a.ep_scale[co];
-          if (a.ep_shift) sh = a.ep_shift[co];
-          else if (a.bias) sh = a.bias[co];
-        }
+        const int col = ct * 32 + (i & 3) + 8 * (i >> 2);    // + 4 kg
+        const float sh = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_sh, cbase + (unsigned)col * 4u, 0, 0));
+        const float sc = a.ep_scale ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_sc, cbase + (unsigned)col * 4u, 0, 0)) : 1.f;
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
           float o = acc[r][ct][i] * sc + sh;
           if (a.relu) o = fmaxf(o, 0.f);
-          ot[(col * 2 + r) * 32 + px] = o;
+          ot[((col + 4 * kg) * 2 + r) * 32 + px] = o;
         }
       }
     __syncthreads();
-    const bool wide = (W & 3) == 0 && (reinterpret_cast<unsigned long long>(a.out) & 15ull) == 0;
-#pragma unroll 4
-    for (int it = 0; it < 16; ++it) {
-      const int row = it * 8 + (lane >> 3);                  // (channel, tile row) pair: col * 2 + r
-      const int col = row >> 1, r = row & 1, x4 = tx + (lane & 7) * 4;
-      const int co = cb * 64 + col, y = ty + 2 * wid + r;
-      const f32x4 v = *reinterpret_cast<const f32x4*>(ot + row * 32 + (lane & 7) * 4);
-      if (co >= a.Cout || y >= H || x4 >= W) continue;
-      float* dst = a.out + (((long long)b * a.Cout + co) * H + y) * W + x4;
-      if (wide) {
-        *reinterpret_cast<f32x4*>(dst) = v;
-      } else {
+    // rows of 32 pixels back as float4: lane = (row pair index lane >> 3, 4 pixels lane & 7); 16 stores of 16 bytes.  The
+    // channel stride rides in the scalar offset of a buffer store whose range check drops channels past Cout.
+    const bool wide = (W & 3) == 0 && (reinterpret_cast<unsigned long long>(a.out) & 15ull) == 0 &&
+                      (long long)a.Cout * HW * 4 < (1ll << 31);
+    const int r = (lane >> 3) & 1, x4 = tx + (lane & 7) * 4, y = ty + 2 * wid + r;
+    const int col0 = lane >> 4;                                // + 4 it
+    if (wide) {
+      float* ob = a.out + (long long)b * a.Cout * HW;
+      const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc(ob, 0, (int)((unsigned)a.Cout * plane_bytes), 0x00020000);
+      const unsigned vo = (y < H && x4 < W) ? ((unsigned)(cb * 64 + col0) * (unsigned)HW + (unsigned)(y * W + x4)) * 4u : OOB;
+#pragma unroll
+      for (int it = 0; it < 16; ++it) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(ot + (it * 8 + (lane >> 3)) * 32 + (lane & 7) * 4);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs_o, vo, (unsigned)(it * 4) * plane_bytes, 0);
+      }
+    } else {
+#pragma unroll 2
+      for (int it = 0; it < 16; ++it) {
+        const int co = cb * 64 + col0 + it * 4;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(ot + (it * 8 + (lane >> 3)) * 32 + (lane & 7) * 4);
+        if (co >= a.Cout || y >= H) continue;
+        float* dst = a.out + (((long long)b * a.Cout + co) * H + y) * W + x4;
 #pragma unroll
         for (int j = 0; j < 4; ++j)
           if (x4 + j < W) dst[j] = v[j];
@@ -467,8 +480,8 @@ __global__ __launch_bounds__(256, 2) void dcn_fwd_region_kernel(RegionArgs a) {
     float* o = a.out + ((long long)b * gridDim.x + blockIdx.x) * 8;
     for (int i = 0; i < 5; ++i) o[i] = (float)(stamp[i + 1] - stamp[i]);
     o[5] = (float)(rt1 - rt0);          // 100 MHz ticks
-    o[6] = (float)(stamp[0] & 0xffffff);
-    o[7] = 0.f;
+    o[6] = (float)(rt0 & 0xffffff);     // start, 100 MHz ticks (low bits)
+    o[7] = (float)(__builtin_amdgcn_s_getreg((15 << 11) | 4) | (__builtin_amdgcn_s_getreg((3 << 11) | 20) << 16));   // HW_ID[15:0] | XCC_ID << 16
   }
 #endif
 }

@@ -34,11 +34,22 @@ for (B, ci, co, H, W) in [(1, 64, 64, 256, 512), (4, 64, 64, 256, 512), (1, 128,
     stn = st.numpy()
     start = stn[:, 6]
     start = (start - start.min()) % (1 << 24)
-    order = np.argsort(start)
-    print("   start offset (cycles) percentiles 0/25/50/75/100:", np.percentile(start, [0, 25, 50, 75, 100]).round())
-    late = start > 20000
-    print("   workgroups starting > 20k cycles late: %d; their K loop mean %.0f vs others %.0f" %
-          (late.sum(), stn[late, 3].mean() if late.any() else 0, stn[~late, 3].mean()))
-    end = start + stn[:, :5].sum(1)
-    print("   end time percentiles 50/90/100: ", np.percentile(end, [50, 90, 100]).round(), " K-loop percentiles 10/50/90:",
-          np.percentile(stn[:, 3], [10, 50, 90]).round())
+    dur = stn[:, 5]
+    print("   start (us after the first workgroup) percentiles 0/50/90/100:", (np.percentile(start, [0, 50, 90, 100]) / 100).round(2),
+          " duration us 10/50/90/100:", (np.percentile(dur, [10, 50, 90, 100]) / 100).round(1))
+    hw = stn[:, 7].astype(np.int64)
+    xcc, cu, sh, se = hw >> 16, (hw >> 8) & 15, (hw >> 12) & 1, (hw >> 13) & 7
+    cuid = ((xcc * 8 + se) * 2 + sh) * 16 + cu
+    ids, cnt = np.unique(cuid, return_counts=True)
+    print("   distinct CUs %d; workgroups per CU histogram: %s" % (len(ids), dict(zip(*np.unique(cnt, return_counts=True)))))
+    for x in range(8):
+        m = xcc == x
+        if m.any():
+            print("   XCC %d: %3d workgroups, K loop median %6.0f max %6.0f, duration median %.1f us" %
+                  (x, m.sum(), np.median(stn[m, 3]), stn[m, 3].max(), np.median(dur[m]) / 100))
+    per_cu = {c: stn[cuid == c, 3] for c in ids}
+    solo = np.array([v.mean() for v in per_cu.values() if len(v) == 1])
+    duo = np.array([v.mean() for v in per_cu.values() if len(v) == 2])
+    tri = np.array([v.mean() for v in per_cu.values() if len(v) >= 3])
+    print("   K loop mean by workgroups sharing the CU: 1 -> %s, 2 -> %s, >=3 -> %s" % (solo.mean().round() if len(solo) else None,
+          duo.mean().round() if len(duo) else None, tri.mean().round() if len(tri) else None))
