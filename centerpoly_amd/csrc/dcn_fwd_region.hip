@@ -230,19 +230,29 @@ __global__ __launch_bounds__(256, 2) void dcn_fwd_region_kernel(RegionArgs a) {
     ox0 = (spanx > 0 && spanx <= RW) ? xmin - ((RW - spanx) >> 1) : tx - 4;  //                         |dx| < 3
   }
 
-  // recipes -> region byte offsets; samples outside the window are flagged cold (u0 = -0.0f, weights zero)
+  // recipes -> region byte offsets.  Samples outside the window are cold, in two classes:
+  //   * all four corners inside the image (the common case): the weights stay, the offset register holds
+  //     0x80000000 | (y0 W + x0) and the step gathers the corners from memory with them;
+  //   * touching the image border: weights zeroed (u0 = -0.0f is the flag), the step rebuilds the sample from the
+  //     offset tensor with per-corner bounds (rare: a one-pixel frame around the image).
   unsigned long long coldany[TAPS];       // per wave and tap: low word = lanes of row 0, high word = row 1
 #pragma unroll
   for (int t = 0; t < TAPS; ++t) {
     const unsigned pk = roff[t];
-    const int iy = (int)(pk >> 16) - 1 - oy0, ix = (int)(pk & 0xffffu) - 1 - ox0;
+    const int y0 = (int)(pk >> 16) - 1, x0 = (int)(pk & 0xffffu) - 1;
+    const int iy = y0 - oy0, ix = x0 - ox0;
     const bool live = pk != 0xFFFFFFFFu;
     const bool warm = (unsigned)iy <= (unsigned)(RH - 2) && (unsigned)ix <= (unsigned)(RW - 2);
     const bool cold = live && !warm;
+    const bool interior = y0 >= 0 && x0 >= 0 && y0 + 1 < H && x0 + 1 < W;
     roff[t] = (live && warm) ? (unsigned)(iy * RW + ix) * 16u : 0u;
     if (cold) {
-      ru0[t] = -0.f;
-      ru1[t] = 0.f;
+      if (interior) {
+        roff[t] = 0x80000000u | (unsigned)(y0 * W + x0);
+      } else {
+        ru0[t] = -0.f;
+        ru1[t] = 0.f;
+      }
     }
     coldany[t] = __builtin_amdgcn_ballot_w64(cold);
   }
@@ -351,7 +361,7 @@ __global__ __launch_bounds__(256, 2) void dcn_fwd_region_kernel(RegionArgs a) {
           if (s < ITEMS) stage_load(s, cn, sv[s % 3]);
         }
         // ---- sample 8 channels of (row r, tap t) for this lane's pixel
-        const unsigned ad = bof[r] + curk;
+        const unsigned ad = (unsigned)max((int)bof[r], 0) + curk;   // (cold samples read cell 0)
         f32x4 a00, a01, a10, a11, b00, b01, b10, b11;
         if (RABL & 4) {
           const float z = __builtin_bit_cast(float, ad);
@@ -383,6 +393,19 @@ __global__ __launch_bounds__(256, 2) void dcn_fwd_region_kernel(RegionArgs a) {
           }
         }
         if (__builtin_expect((unsigned)(coldany[t] >> (32 * r)) != 0u, 0)) {
+          if ((int)bof[r] < 0) {            // interior cold sample: same weights, corners gathered from memory
+            const float* p = xb + (long long)(c * 16 + kg * 8) * HW + (bof[r] & 0x7fffffffu);
+            float g[8][4];
+#pragma unroll
+            for (int j = 0; j < 8; ++j, p += HW) {
+              g[j][0] = p[0];
+              g[j][1] = p[1];
+              g[j][2] = p[W];
+              g[j][3] = p[W + 1];
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = w00 * g[j][0] + w01 * g[j][1] + w10 * g[j][2] + w11 * g[j][3];
+          }
           if (bu0[r] == 0x80000000u) cold_fix(r, t, c * 16 + kg * 8, v);
         }
         unsigned hi[4], lo[4];
