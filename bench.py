@@ -63,7 +63,12 @@ def parse(argv=None):
     p.add_argument("--train_steps", type=int, default=8, help="steps of the N=1 training point")
     p.add_argument("--dcn_contraction", default="auto", choices=["auto", "f32", "bf16x3"],
                    help="DCNv2 forward contraction at inference: exact fp32 MFMA, split-bf16 x3, or auto (split-bf16 "
-                        "for the layers with > 64 output channels)")
+                        "wherever the LDS-region kernel runs and for the layers with > 64 output channels)")
+    p.add_argument("--arithmetic", default="split_bf16", choices=["split_bf16", "exact_f32"],
+                   help="contraction arithmetic of the whole step (centerpoly_amd/arithmetic.py); the line always "
+                        "carries the other one as `exact_f32` / says so in `dtype`")
+    p.add_argument("--no_exact_point", action="store_true",
+                   help="skip the exact-fp32 re-run of the step (`exact_f32`) and the golden-error probe")
     p.add_argument("--graph", action="store_true",
                    help="time one HIP-graph replay per inference step instead of eager launches (measured: no "
                         "faster, the eager step is GPU-bound)")
@@ -191,7 +196,10 @@ CONV_SOURCES = ("conv_mfma.hip", "cp_common.h")
 HEADS_SOURCES = ("heads_fused.hip", "cp_common.h")
 
 
-def kernel_revision(sources=("dcn_fwd.hip", "cp_common.h")):
+DCN_FWD_SOURCES = ("dcn_fwd.hip", "dcn_fwd_region.hip", "cp_common.h")
+
+
+def kernel_revision(sources=DCN_FWD_SOURCES):
     """Content hash of a kernel's sources (default: the DCNv2 forward kernel): PMC traffic files are only
     trusted for the kernel revision they were taken on."""
     h = hashlib.sha256()
@@ -201,7 +209,7 @@ def kernel_revision(sources=("dcn_fwd.hip", "cp_common.h")):
     return h.hexdigest()[:16]
 
 
-def measured_traffic(cin, cout, h, w, nb, prof_name="dcn_fwd_pmc.json", sources=("dcn_fwd.hip", "cp_common.h")):
+def measured_traffic(cin, cout, h, w, nb, prof_name="dcn_fwd_pmc.json", sources=DCN_FWD_SOURCES):
     """HBM bytes per launch of a kernel family's dominant launch from the committed rocprofv3 PMC
     passes -- only when those passes were taken on bench.py's own tensors at the CURRENT kernel
     revision (tools/pmc_bench_traffic.py writes the files); otherwise null."""
@@ -222,7 +230,7 @@ def measured_traffic(cin, cout, h, w, nb, prof_name="dcn_fwd_pmc.json", sources=
                      "FETCH_SIZE correction applied, kernel revision %s" % (d.get("command", "?"), d["kernel_rev"])
 
 
-def dcn_roofline(summary, tag="dcn_fwd"):
+def dcn_roofline(summary, tag="dcn_fwd", fwd_contraction="auto"):
     """Dominant launch of one DCNv2 kernel family: the layer shape with the largest total time in the
     timed region.  Algorithmic bytes / FLOPs per launch: SURVEY.md 8(d); the backward kernels read
     the forward's tensors plus grad_out and write the gradients of the same shapes."""
@@ -249,8 +257,23 @@ def dcn_roofline(summary, tag="dcn_fwd"):
               "launches": summary[key]["launches"]}
     hbm = dict(common, bound="hbm", achieved=alg_bytes / avg_s / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
                frac=alg_bytes / avg_s / 1e9 / HBM_PEAK_GBS, algorithmic_bytes_per_launch=alg_bytes)
-    if tag in ("dcn_bwd_data", "dcn_bwd_weight") and os.environ.get("CP_DCN_BWD_F32", "0") != "1" and w % 4 == 0:
+    from centerpoly_amd import _C
+    from centerpoly_amd.models.networks.DCNv2.dcn_v2 import DCN, auto_contraction
+    if tag in ("dcn_bwd_data", "dcn_bwd_weight") and not (DCN.backward_flags & _C.DCN_BWD_EXACT_F32) and w % 4 == 0:
         mfma = split_bf16_roofline(common, alg_flops, avg_s)   # the backward kernels contract in split-bf16 x3
+    elif tag == "dcn_fwd" and fwd_contraction != "f32":
+        # which kernel the library ran for this shape: 0 gather / exact f32, 1 gather / split-bf16, 2 LDS-region / split-bf16
+        shp = _C.DcnShape(nb, cin, h, w, cout, 3, 3, 1, 1, 1, 1)
+        con = auto_contraction(shp) if fwd_contraction == "auto" else fwd_contraction
+        kid = _C.lib().cp_dcn_v2_forward_kernel(shp, _C.DCN_CONTRACTION[con])
+        if kid >= 1:
+            mfma = split_bf16_roofline(common, alg_flops, avg_s)
+            mfma["arithmetic"] = ("split-bf16 x3 on v_mfma_f32_32x32x16_bf16, fp32 accumulate (LDS-region kernel, "
+                                  "dcn_fwd_region.hip)" if kid == 2 else mfma["arithmetic"] + " (gather kernel)")
+        else:
+            mfma = dict(common, bound="mfma", achieved=alg_flops / avg_s / 1e12, peak=MFMA_F32_PEAK_TF, unit="TFLOP/s",
+                        frac=alg_flops / avg_s / 1e12 / MFMA_F32_PEAK_TF, algorithmic_flops_per_launch=alg_flops,
+                        arithmetic="exact fp32 MFMA (gather kernel)")
     else:
         mfma = dict(common, bound="mfma", achieved=alg_flops / avg_s / 1e12, peak=MFMA_F32_PEAK_TF, unit="TFLOP/s",
                     frac=alg_flops / avg_s / 1e12 / MFMA_F32_PEAK_TF, algorithmic_flops_per_launch=alg_flops)
@@ -313,13 +336,57 @@ def heads_roofline(summary):
     return hbm, split_bf16_roofline(common, alg_flops, avg_s)
 
 
+def infer_contraction(args):
+    """DCNv2 forward contraction of the inference legs: --dcn_contraction, except that the exact-fp32 arithmetic
+    means the exact-fp32 kernel."""
+    from centerpoly_amd import arithmetic
+    return "f32" if arithmetic.current() == "exact_f32" else args.dcn_contraction
+
+
+def golden_error(dev):
+    """Largest error of the DLA-34 head maps against the golden outputs recorded from the reference's own modules
+    (tests/golden/net_dla34.npz: the reference's DLASeg on a 64x96 input, a CPU DCN in its plugin slot), as a
+    fraction of each head's max-norm -- the inference path (prepare_inference) under the CURRENT arithmetic; with the
+    split-bf16 arithmetic also with every DCN layer forced onto the LDS-region kernel (at the golden's map sizes "auto"
+    picks the gather kernels, at the bench's 256x512 maps the region kernel)."""
+    import numpy as np
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import cases
+    from centerpoly_amd import arithmetic
+    from centerpoly_amd.models.model import create_model
+    from centerpoly_amd.models.networks.DCNv2.dcn_v2 import DCN
+    gold = dict(np.load(os.path.join(ROOT, "tests", "golden", "net_dla34.npz"), allow_pickle=True))
+    shapes = {k: tuple(v) for k, v in json.loads(str(gold["shapes"])).items()}
+    m = create_model("dla_34", dict(cases.HEADS), 256)
+    m.load_state_dict({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in cases.fill_weights(shapes).items()})
+    m = m.to(dev).eval()
+    x = torch.from_numpy(cases.net_input("dla")).to(dev)
+
+    def err(contraction):
+        m.prepare_inference(dcn_contraction=contraction)
+        with torch.no_grad():
+            out = m(x)[0]
+        return max(float(np.abs(out[h].cpu().numpy() - gold["s0_" + h]).max() / np.abs(gold["s0_" + h]).max())
+                   for h in dict(cases.HEADS))
+
+    out = {"reference": "tests/golden/net_dla34.npz (reference DLASeg outputs, 64x96 input)", "bar": 1e-3}
+    if arithmetic.current() == "exact_f32":
+        out["exact_f32"] = err("f32")
+    else:
+        out["split_bf16"] = err("auto")
+        out["split_bf16_dcn_on_region_kernel"] = err("bf16x3_region")
+    del m
+    return out
+
+
 # --------------------------------------------------------------------- legs ---
 def infer_leg(args, dev, world, arch="dla_34", heads=None, rep="cartesian", steps=None, warmup=None,
               offset_weight_scale=0.5, tag="infer"):
     import torch
     from centerpoly_amd import _C, synth
     from centerpoly_amd.models.decode import polydet_decode
-    model, _ = build_model(dev, train=False, dcn_contraction=args.dcn_contraction, arch=arch, heads=heads,
+    model, _ = build_model(dev, train=False, dcn_contraction=infer_contraction(args), arch=arch, heads=heads,
                            offset_weight_scale=offset_weight_scale)
     x = torch.from_numpy(synth.normal("bench/input", (1, 3, args.height, args.width))).to(dev)
 
@@ -374,11 +441,12 @@ def infer_leg(args, dev, world, arch="dla_34", heads=None, rep="cartesian", step
     return t, summary
 
 
-def offset_field_points(dev, n=40):
-    """The dominant DCNv2 forward launch (64->64 @256x512, one image) on three synthetic offset
-    fields: white noise of 0.3 px and 1 px, and a smooth field of about 3 px (what a trained offset
-    branch produces).  The gathers' cost grows with the spatial noise of the offsets, so the
-    roofline fraction of the bench model (offset weights halved) is the optimistic end."""
+def offset_field_points(dev, contraction="auto", n=40):
+    """The dominant DCNv2 forward launch (64->64 @256x512, one image) on three synthetic offset fields: white noise of
+    0.3 px and 1 px, and a smooth field of about 3 px (what a trained offset branch produces), with the contraction
+    the inference step uses and the weights prepared once (as the inference modules do).  The region kernel's cost
+    grows with the share of samples leaving its staged window (cold gathers), the gather kernels' with the spatial
+    noise of the offsets: the bench model (offset weights halved) is the optimistic end."""
     import numpy as np
     import torch
     from centerpoly_amd import synth
@@ -395,24 +463,31 @@ def offset_field_points(dev, n=40):
     x = torch.from_numpy(synth.normal("bench/offsets/x", (1, ci, H, W))).to(dev)
     w = torch.from_numpy(synth.normal("bench/offsets/w", (co, ci, 3, 3), 0, 0.04)).to(dev)
     b = torch.zeros(co, device=dev)
-    flops = 2.0 * 9 * ci * co * H * W
+
+    class Owner:
+        pass
+
+    own = Owner()
     out = []
     for name, om in (("white noise, std 0.3 px", small), ("white noise, std 1 px", noise),
                      ("smooth field, std 3 px (9x9 box-filtered noise)", smooth)):
         omt = torch.from_numpy(np.ascontiguousarray(om)).to(dev)
         for _ in range(10):
-            dcn_v2_forward_raw(x, omt, w, b)
+            dcn_v2_forward_raw(x, omt, w, b, contraction=contraction, owner=own)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         torch.cuda.synchronize()
         e0.record()
         for _ in range(n):
-            dcn_v2_forward_raw(x, omt, w, b)
+            dcn_v2_forward_raw(x, omt, w, b, contraction=contraction, owner=own)
         e1.record()
         torch.cuda.synchronize()
-        us = e0.elapsed_time(e1) / n * 1e3
-        out.append({"offsets": name, "avg_launch_us": us, "bound": "mfma", "achieved": flops / us / 1e6,
-                    "unit": "TFLOP/s", "peak": MFMA_F32_PEAK_TF, "frac": flops / us / 1e6 / MFMA_F32_PEAK_TF})
-    return {"kernel": "dcn_v2_forward 64->64 @256x512 (stand-alone launches, %d each)" % n, "points": out}
+        ms = e0.elapsed_time(e1) / n
+        hbm, mfma = dcn_roofline({("dcn_fwd", ci, co, H, W, 1): {"avg_ms": ms, "launches": n}}, fwd_contraction=contraction)
+        out.append({"offsets": name, "avg_launch_us": ms * 1e3, "bound": mfma["bound"], "achieved": mfma["achieved"],
+                    "unit": mfma["unit"], "peak": mfma["peak"], "frac": mfma["frac"], "arithmetic": mfma.get("arithmetic"),
+                    "hbm_frac": hbm["frac"], "hbm_achieved_gbs": hbm["achieved"]})
+    return {"kernel": "dcn_v2_forward 64->64 @256x512 (stand-alone launches, %d each, contraction %s)" % (n, contraction),
+            "points": out}
 
 
 def train_leg(args, dev, world, rank, steps, warmup, cfg="3"):
@@ -460,7 +535,8 @@ def train_rooflines(summary):
     out = {}
     for tag, name in (("dcn_fwd", "roofline"), ("dcn_bwd_data", "roofline_bwd_data"),
                       ("dcn_bwd_weight", "roofline_bwd_weight")):
-        hbm, mfma = dcn_roofline(summary, tag)
+        from centerpoly_amd.models.networks.DCNv2.dcn_v2 import DCN
+        hbm, mfma = dcn_roofline(summary, tag, DCN.train_contraction)
         if mfma is not None:
             out[name] = mfma
             out[name + "_hbm"] = hbm
@@ -635,8 +711,10 @@ def main(argv=None):
             cfg = "2" if args.mode == "infer" else "3"
     mode = "infer" if cfg in ("2", "4") else "train"
     torch.backends.cudnn.benchmark = os.environ.get("CP_MIOPEN_BENCHMARK", "0") == "1"
+    from centerpoly_amd import arithmetic
+    arithmetic.configure(args.arithmetic)
     line = {"n_gpus": world, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "scaling": "weak", "vs_baseline": None, "dtype": arithmetic.describe(), "arithmetic": args.arithmetic,
             "data": "synthetic (counter-hash inputs, name-hashed random-init weights)"}
     if mode == "infer":
         if cfg == "4":
@@ -652,7 +730,7 @@ def main(argv=None):
                         "K=128, forward + sigmoid + NMS/top-k/decode" % (args.height, args.width))
             metric = "inference img/s @2048x1024 DLA-34 (1 GPU)"
         meta = summary.pop("__meta__")
-        hbm, mfma = dcn_roofline(summary)
+        hbm, mfma = dcn_roofline(summary, fwd_contraction=infer_contraction(args))
         chbm, cmfma = conv_roofline(summary)
         hhbm, hmfma = heads_roofline(summary)
         if mfma is None:                                   # Hourglass: no DCN, the 3x3 convolution dominates
@@ -681,14 +759,29 @@ def main(argv=None):
         })
         if world == 1 and cfg == "2":
             if not args.no_offset_points:
-                line["roofline_by_offsets"] = offset_field_points(dev)
+                line["roofline_by_offsets"] = offset_field_points(dev, infer_contraction(args))
                 t1, s1 = infer_leg(args, dev, 1, steps=10, warmup=2, offset_weight_scale=1.0, tag="infer(unscaled)")
-                _, m1 = dcn_roofline(s1)
+                _, m1 = dcn_roofline(s1, fwd_contraction=infer_contraction(args))
                 line["infer_unscaled_offset_weights"] = {
                     "what": "the same step with conv_offset_mask weights at their full fan-in scale (offsets "
                             "twice as large as in `value`'s model)",
                     "value": 10 / t1, "ms_per_step": 1e3 * t1 / 10, "steps": 10, "roofline": m1}
                 note("offset-field points done")
+            if not args.no_exact_point:
+                # the precision contract beside the headline: error of the timed arithmetic against the reference's
+                # golden outputs, and the same step on exact fp32 chains (library convolutions, f32-MFMA DCNv2)
+                line["max_rel_err_vs_golden"] = golden_error(dev)
+                other = "exact_f32" if args.arithmetic == "split_bf16" else "split_bf16"
+                arithmetic.configure(other)
+                try:
+                    t2, _ = infer_leg(args, dev, 1, steps=10, warmup=3, tag="infer(%s)" % other)
+                    line[other] = {"what": "the same step under the %s arithmetic (%s)" % (other, arithmetic.describe()),
+                                   "value": 10 / t2, "ms_per_step": 1e3 * t2 / 10, "steps": 10, "warmup": 3}
+                    line["max_rel_err_vs_golden"].update({k: v for k, v in golden_error(dev).items()
+                                                          if k not in ("reference", "bar")})
+                finally:
+                    arithmetic.configure(args.arithmetic)
+                note("%s point done" % other)
             if not args.no_detector_point:
                 line["detector_end_to_end"] = detector_leg(args, dev)
                 note("detector end-to-end point done")

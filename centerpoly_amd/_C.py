@@ -15,6 +15,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libcenterpoly_hip.so")
 CP_OK = 0
 REP = {"cartesian": 0, "polar": 1, "polar_fixed": 2}
 L1_PLAIN, L1_POLAR, L1_POLAR_FIXED, L1_RELU20, L1_SMOOTH = 0, 1, 2, 3, 4
+DCN_BWD_EXACT_F32, DCN_BWD_NARROW_TILES, DCN_BWD_ROUND1_KERNELS = 1, 2, 4
 DCN_CONTRACTION = {"f32": 0, "bf16x3": 1, "bf16x3_region": 3}     # (+1 = "..._PREPARED": weights already in the workspace)
 
 
@@ -49,7 +50,7 @@ _SIGNATURES = {
                                     _P, _P, c_int32, c_int32, _P, _P, c_size_t, _P]),
     "cp_dcn_v2_backward_workspace_bytes": (c_size_t, [POINTER(DcnShape)]),
     "cp_dcn_v2_backward": (c_int32, [POINTER(DcnShape), _P, _P, c_int64, _P, c_int64, c_int32, _P, _P,
-                                     _P, _P, c_int64, _P, c_int64, _P, _P, _P, c_size_t, _P]),
+                                     _P, _P, c_int64, _P, c_int64, _P, _P, c_int32, _P, c_size_t, _P]),
     "cp_depthwise_up_forward": (c_int32, [_P, _P, _P, _P] + [c_int32] * 5 + [_P]),
     "cp_depthwise_up_backward": (c_int32, [_P, _P, _P, _P, _P] + [c_int32] * 5 + [_P]),
     "cp_bn_workspace_bytes": (c_size_t, [c_int32, c_int32, c_int64]),
@@ -122,7 +123,7 @@ def lib():
             fn = getattr(l, name)
             fn.restype = res
             fn.argtypes = args
-        if l.cp_abi_version() != 1:
+        if l.cp_abi_version() != 2:
             raise NativeError("ABI version mismatch")
         _lib = l
     return _lib

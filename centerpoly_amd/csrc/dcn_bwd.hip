@@ -980,21 +980,15 @@ size_t cp_dcn_bwd_data2_workspace_bytes(const cp_dcn_shape* s);
 int cp_dcn_bwd_data2(const cp_dcn_shape* s, const float* x, const float* offset, int64_t offset_bstride,
                      const float* mask, int64_t mask_bstride, int32_t mask_is_logit, const float* weight,
                      const float* grad_out, float* grad_x, float* grad_offset, int64_t grad_offset_bstride,
-                     float* grad_mask, int64_t grad_mask_bstride, void* workspace, size_t workspace_bytes,
+                     float* grad_mask, int64_t grad_mask_bstride, int32_t flags, void* workspace, size_t workspace_bytes,
                      hipStream_t st);
 
 // dcn_bwd_weight.hip: the weight gradient with columns sampled straight into the MFMA operand
 bool cp_dcn_bwd_weight2_supported(const cp_dcn_shape* s);
 int cp_dcn_bwd_weight2(const cp_dcn_shape* s, const float* x, const float* offset, int64_t offset_bstride,
                        const float* mask, int64_t mask_bstride, int32_t mask_is_logit, const float* grad_out,
-                       float* grad_weight, float* grad_bias, hipStream_t st);
+                       float* grad_weight, float* grad_bias, int32_t flags, hipStream_t st);
 
-// A/B switch for timing runs (tools/probe_dcn_bwd.py): CP_DCN_BWD_V1=1 keeps the round-1 data kernel.
-// Read once per process, never on the call path.
-static bool use_v1_data_kernel() {
-  static const bool v1 = [] { const char* e = getenv("CP_DCN_BWD_V1"); return e && e[0] == '1'; }();
-  return v1;
-}
 
 extern "C" size_t cp_dcn_v2_backward_workspace_bytes(const cp_dcn_shape* s) {
   if (!s || s->kh != 3 || s->kw != 3 || s->deformable_groups != 1) return 0;
@@ -1007,7 +1001,7 @@ extern "C" int cp_dcn_v2_backward(const cp_dcn_shape* s, const float* x, const f
                                   const float* weight, const float* grad_out, float* grad_x,
                                   float* grad_offset, int64_t grad_offset_bstride,
                                   float* grad_mask, int64_t grad_mask_bstride, float* grad_weight,
-                                  float* grad_bias, void* workspace,
+                                  float* grad_bias, int32_t flags, void* workspace,
                                   size_t workspace_bytes, void* stream) {
   CP_CHECK_ARG(s && x && offset && mask && weight && grad_out);
   CP_CHECK_ARG(s->B > 0 && s->Cin > 0 && s->H > 0 && s->W > 0 && s->Cout > 0);
@@ -1032,6 +1026,11 @@ extern "C" int cp_dcn_v2_backward(const cp_dcn_shape* s, const float* x, const f
   }
 #endif
   hipStream_t st = (hipStream_t)stream;
+  CP_CHECK_ARG((flags & ~(CP_DCN_BWD_EXACT_F32 | CP_DCN_BWD_NARROW_TILES | CP_DCN_BWD_ROUND1_KERNELS)) == 0);
+  const bool round1 = (flags & CP_DCN_BWD_ROUND1_KERNELS) != 0;
+  // grad_x is OVERWRITTEN: every kernel below accumulates into it (region sums + cold-path / fallback float atomics),
+  // so the library zero-fills it here and the caller may hand over uninitialised memory
+  if (grad_x && hipMemsetAsync(grad_x, 0, (size_t)s->B * s->Cin * s->H * s->W * sizeof(float), st) != hipSuccess) return CP_EHIP;
   const int tiles = (Ho * Wo + BM - 1) / BM;
   a.tpr = (s->W + BM - 1) / BM;
   const int row_tiles = s->H * a.tpr;       // tiled kernels: tiles never straddle rows
@@ -1039,10 +1038,10 @@ extern "C" int cp_dcn_v2_backward(const cp_dcn_shape* s, const float* x, const f
                          (unsigned long long)s->Cout * Ho * Wo * 4ull < 0xE0000000ull &&
                          (long long)s->H * s->W < (1ll << 27);     // fallback index packed with 4 bits
   bool data_done = false;
-  if ((grad_x || grad_offset || grad_mask) && cp_dcn_bwd_data2_supported(s) && !use_v1_data_kernel() &&
+  if ((grad_x || grad_offset || grad_mask) && cp_dcn_bwd_data2_supported(s) && !round1 &&
       workspace && workspace_bytes >= cp_dcn_bwd_data2_workspace_bytes(s)) {
     const int rc = cp_dcn_bwd_data2(s, x, offset, offset_bstride, mask, mask_bstride, mask_is_logit, weight, grad_out,
-                                    grad_x, grad_offset, grad_offset_bstride, grad_mask, grad_mask_bstride, workspace,
+                                    grad_x, grad_offset, grad_offset_bstride, grad_mask, grad_mask_bstride, flags, workspace,
                                     workspace_bytes, st);
     if (rc != CP_OK) return rc;
     data_done = true;
@@ -1059,10 +1058,10 @@ extern "C" int cp_dcn_v2_backward(const cp_dcn_shape* s, const float* x, const f
     }
   }
   bool weight_done = false;
-  if (grad_weight && cp_dcn_bwd_weight2_supported(s) && !use_v1_data_kernel()) {
+  if (grad_weight && cp_dcn_bwd_weight2_supported(s) && !round1) {
     // (grad_bias rides along: the weight kernel has every grad_out tile in LDS anyway)
     const int rc = cp_dcn_bwd_weight2(s, x, offset, offset_bstride, mask, mask_bstride, mask_is_logit, grad_out,
-                                      grad_weight, grad_bias, st);
+                                      grad_weight, grad_bias, flags, st);
     if (rc != CP_OK) return rc;
     weight_done = true;
     grad_bias = nullptr;

@@ -749,18 +749,13 @@ bool cp_dcn_bwd_data2_supported(const cp_dcn_shape* s) {
   return true;
 }
 
-// CP_DCN_BWD_TH8=1 keeps the 8-row tiles everywhere (A/B timing); read once per process.
-static bool d2_narrow_tiles() {
-  static const bool v = [] { const char* e = getenv("CP_DCN_BWD_TH8"); return e && e[0] == '1'; }();
-  return v;
-}
-
-static D2Plan d2_plan(const cp_dcn_shape* s, bool want_gx, bool want_om) {
+// narrow = CP_DCN_BWD_NARROW_TILES: the 8-row tiles everywhere (A/B timing)
+static D2Plan d2_plan(const cp_dcn_shape* s, bool want_gx, bool want_om, bool narrow) {
   D2Plan p;
   // 12-row tiles (three waves per SIMD) for the 64-channel-output layers when they still fill the chip twice:
   // measured 2..7 % faster than 8-row tiles at B >= 4, slower at B = 1 (fewer workgroups)
   const long long wide_wgs = (long long)((s->W + TW - 1) / TW) * ((s->H + TH_WIDE - 1) / TH_WIDE) * s->B;
-  p.TH = (s->Cout <= 64 && want_gx && wide_wgs >= 1024 && !d2_narrow_tiles()) ? TH_WIDE : TH_DEFAULT;
+  p.TH = (s->Cout <= 64 && want_gx && wide_wgs >= 1024 && !narrow) ? TH_WIDE : TH_DEFAULT;
   p.tpr = (s->W + TW - 1) / TW;
   p.tpc = (s->H + p.TH - 1) / p.TH;
   p.ntiles = p.tpr * p.tpc;
@@ -788,17 +783,15 @@ static D2Plan d2_plan(const cp_dcn_shape* s, bool want_gx, bool want_om) {
   return p;
 }
 
-size_t cp_dcn_bwd_data2_workspace_bytes(const cp_dcn_shape* s) {
-  return cp_dcn_bwd_data2_supported(s) ? d2_plan(s, true, true).total : 0;
+size_t cp_dcn_bwd_data2_workspace_bytes(const cp_dcn_shape* s) {      // (enough for either tile form)
+  if (!cp_dcn_bwd_data2_supported(s)) return 0;
+  const size_t a = d2_plan(s, true, true, false).total, b = d2_plan(s, true, true, true).total;
+  return a > b ? a : b;
 }
 
 // Contraction of the grad columns: split-bf16 x3 on the bf16 matrix cores (default) or the exact f32 MFMA chain
-// (CP_DCN_BWD_F32=1; read once per process).  The f32-input MFMA executes on the SIMD's vector ALUs and serialises
-// with the consumption's VALU work; the bf16 cores run beside it.  |error| of a grad column <= 3 * 2^-17 * sum|w go|.
-static bool d2_exact_f32() {
-  static const bool v = [] { const char* e = getenv("CP_DCN_BWD_F32"); return e && e[0] == '1'; }();
-  return v;
-}
+// (flag CP_DCN_BWD_EXACT_F32).  The f32-input MFMA executes on the SIMD's vector ALUs and serialises with the
+// consumption's VALU work; the bf16 cores run beside it.  |error| of a grad column <= 3 * 2^-17 * sum|w go|.
 
 template <int CP, bool WANT_GX, bool BF>
 static void d2_launch_bf(const D2Args& a, const D2Plan& p, int B, hipStream_t st) {
@@ -814,8 +807,8 @@ static void d2_launch_bf(const D2Args& a, const D2Plan& p, int B, hipStream_t st
 }
 
 template <int CP, bool WANT_GX>
-static void d2_launch(const D2Args& a, const D2Plan& p, int B, hipStream_t st) {
-  if (d2_exact_f32()) d2_launch_bf<CP, WANT_GX, false>(a, p, B, st);
+static void d2_launch(const D2Args& a, const D2Plan& p, int B, bool exact, hipStream_t st) {
+  if (exact) d2_launch_bf<CP, WANT_GX, false>(a, p, B, st);
   else d2_launch_bf<CP, WANT_GX, true>(a, p, B, st);
 }
 
@@ -824,17 +817,18 @@ static void d2_launch(const D2Args& a, const D2Plan& p, int B, hipStream_t st) {
 int cp_dcn_bwd_data2(const cp_dcn_shape* s, const float* x, const float* offset, int64_t offset_bstride,
                      const float* mask, int64_t mask_bstride, int32_t mask_is_logit, const float* weight,
                      const float* grad_out, float* grad_x, float* grad_offset, int64_t grad_offset_bstride,
-                     float* grad_mask, int64_t grad_mask_bstride, void* workspace, size_t workspace_bytes,
+                     float* grad_mask, int64_t grad_mask_bstride, int32_t flags, void* workspace, size_t workspace_bytes,
                      hipStream_t st) {
   const bool want_gx = grad_x != nullptr, want_om = grad_offset != nullptr || grad_mask != nullptr;
-  const D2Plan p = d2_plan(s, want_gx, want_om);
+  const bool exact = (flags & CP_DCN_BWD_EXACT_F32) != 0;
+  const D2Plan p = d2_plan(s, want_gx, want_om, (flags & CP_DCN_BWD_NARROW_TILES) != 0);
   if (!workspace || workspace_bytes < p.total) return CP_EINVAL;
   char* ws = (char*)workspace;
   unsigned* wmax_bits = (unsigned*)(ws + p.off_wmax);
   f32x4* wp = (f32x4*)(ws + p.off_wp);
   (void)hipMemsetAsync(wmax_bits, 0, 8, st);                 // max |W| and the cold-path flag
   const int total_f4 = p.chunks * p.NS * A_F4;
-  if (d2_exact_f32())
+  if (exact)
     hipLaunchKernelGGL(dcn_bwd_wperm_kernel, dim3((total_f4 + 255) / 256), dim3(256), 0, st, weight, (float4*)wp,
                        wmax_bits, s->Cin, s->Cout, p.NS, total_f4);
   else                                                     // (a bf16x8 fragment is 16 bytes: same count, same bytes)
@@ -862,9 +856,9 @@ int cp_dcn_bwd_data2(const cp_dcn_shape* s, const float* x, const float* offset,
     a.part_sstride = 0;
   }
   if (want_gx) {
-    if (p.NS == 1) d2_launch<64, true>(a, p, s->B, st);
-    else if (p.NS == 2) d2_launch<128, true>(a, p, s->B, st);
-    else d2_launch<256, true>(a, p, s->B, st);
+    if (p.NS == 1) d2_launch<64, true>(a, p, s->B, exact, st);
+    else if (p.NS == 2) d2_launch<128, true>(a, p, s->B, exact, st);
+    else d2_launch<256, true>(a, p, s->B, exact, st);
     const bool vec = s->W % 4 == 0 && ((uintptr_t)grad_x & 15) == 0;
     const int per_row = vec ? s->W / 4 : s->W;
     const dim3 grid((per_row + 63) / 64, s->H, (s->B * s->Cin + 3) / 4);
@@ -875,9 +869,9 @@ int cp_dcn_bwd_data2(const cp_dcn_shape* s, const float* x, const float* offset,
       hipLaunchKernelGGL(dcn_bwd_gx_reduce_kernel<false>, grid, dim3(256), 0, st, a.slab, grad_x, a.cold_flag,
                          s->B * s->Cin, s->Cin, s->H, s->W, p.tpr, p.tpc, p.TH);
   } else {
-    if (p.NS == 1) d2_launch<64, false>(a, p, s->B, st);
-    else if (p.NS == 2) d2_launch<128, false>(a, p, s->B, st);
-    else d2_launch<256, false>(a, p, s->B, st);
+    if (p.NS == 1) d2_launch<64, false>(a, p, s->B, exact, st);
+    else if (p.NS == 2) d2_launch<128, false>(a, p, s->B, exact, st);
+    else d2_launch<256, false>(a, p, s->B, exact, st);
   }
   if (p.slices > 1 && want_om) {
     const long long n = (long long)s->B * 27 * HW;

@@ -597,7 +597,7 @@ bool cp_dcn_bwd_weight2_supported(const cp_dcn_shape* s) {
 
 int cp_dcn_bwd_weight2(const cp_dcn_shape* s, const float* x, const float* offset, int64_t offset_bstride,
                        const float* mask, int64_t mask_bstride, int32_t mask_is_logit, const float* grad_out,
-                       float* grad_weight, float* grad_bias, hipStream_t st) {
+                       float* grad_weight, float* grad_bias, int32_t flags, hipStream_t st) {
   W2Args a;
   a.x = x; a.offset = offset; a.mask = mask; a.go = grad_out; a.gw = grad_weight; a.gb = grad_bias;
   a.offset_bstride = offset_bstride; a.mask_bstride = mask_bstride;
@@ -618,8 +618,8 @@ int cp_dcn_bwd_weight2(const cp_dcn_shape* s, const float* x, const float* offse
   a.T = T;
   a.runs_per_image = (a.ntiles + T - 1) / T;
   const dim3 grid(a.runs_per_image * s->B, chunks, slabs);
-  // split-bf16 form by default (needs whole float4 groups of grad_out: W % 4 == 0); CP_DCN_BWD_F32=1: exact f32
-  static const bool exact = [] { const char* e = getenv("CP_DCN_BWD_F32"); return e && e[0] == '1'; }();
+  // split-bf16 form by default (needs whole float4 groups of grad_out: W % 4 == 0); CP_DCN_BWD_EXACT_F32: exact f32
+  const bool exact = (flags & CP_DCN_BWD_EXACT_F32) != 0;
   if (!exact && (s->W & 3) == 0)
     hipLaunchKernelGGL(dcn_bwd_weight3_kernel, grid, dim3(512), 0, st, a);
   else

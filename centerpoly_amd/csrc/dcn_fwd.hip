@@ -1,24 +1,17 @@
-// DCNv2 forward for gfx950: bilinear-sampled, mask-modulated im2col tile built in
-// LDS (never in HBM) and contracted against the weight tile with fp32 MFMA.
+// DCNv2 forward for gfx950, gather kernels + dispatch: bilinear-sampled, mask-modulated im2col tile built in LDS
+// (never in HBM) and contracted against the weight tile on the matrix cores.  The large maps go to the LDS-region
+// kernel of dcn_fwd_region.hip (split-bf16); this file holds the per-lane-gather kernels -- exact fp32 MFMA
+// (dcn_fwd_pipe_kernel) and split-bf16 (dcn_fwd_pipe_bf16_kernel) -- that serve the small, deep maps (K split over
+// workgroups), strides / dilations / channel counts the region kernel does not take, and CP_DCN_F32.
 //
 // Replaces the native extension behind `from .DCNv2.dcn_v2 import DCN`
 // (reference: src/lib/models/networks/pose_dla_dcn.py:16,354).
 //
-// Tiling: one workgroup (4 waves) = 64 consecutive output pixels of one image x
-// BN output channels.  K = Cin*kh*kw is walked in chunks of KC input channels:
-//   1. every lane owns one pixel and keeps that pixel's kh*kw sampling recipes
-//      (4 corner weights, pre-multiplied by mask and validity, + the clamped
-//      top-left index and 2 step bits) in registers for the whole K loop;
-//   2. wave w samples channels {c0 + w*KC/4 ...} of the chunk: lanes = adjacent
-//      pixels, so the 4 corner reads of a (channel, tap) are near-contiguous;
-//   3. the weight chunk [BN][KC*9] is staged to LDS with coalesced row reads;
-//   4. v_mfma_f32_16x16x4_f32 over the chunk (exact fp32 fma chain).
-// Gathers are issued 36 at a time (all taps x corners of a channel) before any use,
-// so a wave keeps a full batch of L1/L2 requests in flight.  Layers whose grid
-// would not fill the 256 CUs take narrower N tiles and a split over K whose
-// partial sums meet in a small reduce+epilogue kernel (workspace supplied by caller).
-// LDS rows are padded to an odd dword count so both the lane=pixel writes and the
-// lane=(row, k) fragment reads are bank-conflict free.
+// Tiling: one workgroup (4 waves) = 64 consecutive output pixels of one image x BN output channels; every lane owns
+// one pixel and keeps that pixel's 9 sampling recipes (4 corner weights, pre-multiplied by mask and validity, + the
+// byte offsets of the two row pairs) in registers for the whole K loop.  Layers whose grid would not fill the 256
+// CUs split K over workgroups; the partial sums meet in a small reduce + epilogue kernel (workspace supplied by the
+// caller).  Details at each kernel.
 #include "cp_common.h"
 #include "dcn_internal.h"
 #include <stdlib.h>
@@ -121,186 +114,10 @@ __device__ __forceinline__ void pair_recipe(const DcnFwdArgs& a, int b, int p, b
   }
 }
 
-template <int BN, int KC, int WPS>
-__global__ __launch_bounds__(256, WPS) void dcn_fwd_kernel(DcnFwdArgs a) {
-  static_assert(sizeof(int) == 4, "");
-  constexpr int KK = KC * TAPS;          // k extent of one chunk
-  constexpr int LD = KK + LDPAD;         // row stride (dwords), see LDPAD
-  constexpr int NT = BN / 32;            // 16-wide n tiles per wave
-  constexpr int CPW = KC / 4;            // channels sampled per wave per chunk
-  static_assert(KK % 4 == 0, "chunk must be a multiple of the MFMA k");
-  extern __shared__ float lds[];
-  float* colT = lds;                     // [BM][LD]
-  float* wT = lds + BM * LD;             // [BN][LD]
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wid = tid >> 6;
-  const int b = blockIdx.z % a.B;
-  const int n0 = blockIdx.y * BN;
-  const int HWo = a.Ho * a.Wo;
-  const int HW = a.H * a.W;
-  const int p = blockIdx.x * BM + lane;
-  const bool p_ok = p < HWo;
-
-  // ---- per-pixel sampling recipes, kept in registers: 4 corner weights x mask x validity and
-  // the byte offsets of the two row pairs inside one channel plane.  Gathers are raw buffer
-  // loads: wave-uniform resource descriptor (SGPRs) + this 32-bit per-lane offset + the
-  // channel's plane offset in the scalar soffset operand -- no per-gather 64-bit VALU address
-  // arithmetic (PMC showed the flat-address form issue-bound: 6.7 VALU per MFMA).
-  float cw[TAPS][4];
-  unsigned coff[TAPS][2];
-  pair_recipe(a, b, p, p_ok, cw, coff);
-
-  f32x4 acc[2][NT];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  const int wm = wid >> 1, wn = wid & 1;
-  const int Ktot = a.Cin * TAPS;
-  const float* xb = a.x + (long long)b * a.Cin * HW;
-
-  const int ksl = (a.splitk > 1) ? (int)(blockIdx.z / a.B) : 0;
-  const int c_begin = ksl * a.c_per_split;
-  const int c_end = min(a.Cin, c_begin + a.c_per_split);
-
-  // Software pipeline (register double-buffer): the gathers and the weight rows of
-  // chunk i+1 are ISSUED before chunk i's MFMA phase and only consumed after it, so
-  // their L2/HBM latency hides under the matrix work instead of adding to it.
-  constexpr int WPT = (BN * KK + 255) / 256;     // weight elements per thread per chunk
-  float g[CPW][TAPS][4];
-  float wreg[WPT];
-  // wave-uniform buffer descriptors (built from kernargs / blockIdx only)
-  const unsigned plane_bytes = (unsigned)HW * 4u;
-  const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(xb), 0, (int)((unsigned)a.Cin * plane_bytes), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(a.weight), 0, (int)((unsigned)a.Cout * (unsigned)Ktot * 4u), 0x00020000);
-  // per-thread weight element i: global byte offset (0xf0000000 + k offset never wraps and is
-  // always past num_records -> reads 0; tensors here are far below 3.7 GB) and
-  // LDS slot, both fixed for the whole K loop; the chunk's k offset goes into soffset
-  unsigned woff[WPT];
-  int wlds[WPT];
-#pragma unroll
-  for (int i = 0; i < WPT; ++i) {
-    const int idx = tid + i * 256;
-    const int co = idx / KK, kk = idx - co * KK;
-    const bool ok = idx < BN * KK && n0 + co < a.Cout;
-    woff[i] = ok ? ((unsigned)(n0 + co) * (unsigned)Ktot + (unsigned)kk) * 4u : 0xf0000000u;
-    wlds[i] = idx < BN * KK ? co * LD + kk : -1;
-  }
-  const int swid = __builtin_amdgcn_readfirstlane(wid);
-  auto issue_loads = [&](int c0) {
-    // NOTE: the scalar soffset operand is NOT range-checked by the hardware, only voffset is.
-    // The chunk's k offset therefore rides in voffset (past-the-end weights read 0), and the
-    // channel plane offset is clamped to the last plane (its samples are zeroed by c_ok).
-    const unsigned wk = (unsigned)(c0 * TAPS) * 4u;
-#pragma unroll
-    for (int i = 0; i < WPT; ++i)
-      wreg[i] = CP_ABL(4) ? 0.f
-                          : __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                                                          rs_w, woff[i] + wk, 0, 0));
-#pragma unroll
-    for (int cc = 0; cc < CPW; ++cc) {
-      const int c = c0 + swid * CPW + cc;
-      const unsigned xsoff = (unsigned)min(c, a.Cin - 1) * plane_bytes;
-#pragma unroll
-      for (int t = 0; t < TAPS; ++t) {
-        if (CP_ABL(1)) {
-          g[cc][t][0] = g[cc][t][1] = g[cc][t][2] = g[cc][t][3] = 1.f;
-          continue;
-        }
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-          const f32x2 v = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_x, coff[t][k], xsoff, 0));
-          g[cc][t][2 * k] = v.x;
-          g[cc][t][2 * k + 1] = v.y;
-        }
-      }
-    }
-  };
-  auto write_lds = [&](int c0) {
-#pragma unroll
-    for (int cc = 0; cc < CPW; ++cc) {
-      const int cl = swid * CPW + cc;
-      const bool c_ok = c0 + cl < c_end;         // split-K: channels past this slice contribute 0
-#pragma unroll
-      for (int t = 0; t < TAPS; ++t) {
-        const float v = cw[t][0] * g[cc][t][0] + cw[t][1] * g[cc][t][1] +
-                        cw[t][2] * g[cc][t][2] + cw[t][3] * g[cc][t][3];
-        if (!CP_ABL(2)) colT[lane * LD + cl * TAPS + t] = c_ok ? v : 0.f;
-        else if (v == 12345.f) colT[0] = v;
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < WPT; ++i)
-      if (wlds[i] >= 0) wT[wlds[i]] = wreg[i];
-  };
-
-  if (c_begin < c_end) issue_loads(c_begin);
-  for (int c0 = c_begin; c0 < c_end; c0 += KC) {
-    write_lds(c0);                       // waits for this chunk's loads
-    __syncthreads();
-    if (c0 + KC < c_end) issue_loads(c0 + KC);   // in flight during the MFMA phase
-    const int arow = (wm * 32 + (lane & 15)) * LD + (lane >> 4);
-    const int brow = (wn * (BN / 2) + (lane & 15)) * LD + (lane >> 4);
-#pragma unroll
-    for (int ks = 0; ks < (CP_ABL(8) ? 0 : KK / 4); ++ks) {
-      float af[2], bf[NT];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) af[i] = colT[arow + i * 16 * LD + ks * 4];
-#pragma unroll
-      for (int j = 0; j < NT; ++j) bf[j] = wT[brow + j * 16 * LD + ks * 4];
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[j], acc[i][j], 0, 0, 0);
-    }
-    __syncthreads();                     // fragment reads done before the next write_lds
-  }
-
-  // ---- epilogue: C layout col = lane&15 (cout), row = (lane>>4)*4 + reg (pixel) ----
-  const bool raw = a.splitk > 1;
-  float* ob = raw ? a.partial + ((long long)ksl * a.B + b) * a.Cout * HWo
-                  : a.out + (long long)b * a.Cout * HWo;
-#pragma unroll
-  for (int j = 0; j < NT; ++j) {
-    const int co = n0 + wn * (BN / 2) + j * 16 + (lane & 15);
-    if (co >= a.Cout) continue;
-    float sc = 1.f, sh = 0.f;
-    if (!raw) {
-      if (a.ep_scale) sc = a.ep_scale[co];
-      if (a.ep_shift) sh = a.ep_shift[co];
-      else if (a.bias) sh = a.bias[co];
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int pp = blockIdx.x * BM + wm * 32 + i * 16 + (lane >> 4) * 4;
-      float v[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        v[r] = acc[i][j][r] * sc + sh;
-        if (a.relu && !raw) v[r] = fmaxf(v[r], 0.f);
-      }
-      float* dst = ob + (long long)co * HWo + pp;
-      if (pp + 3 < HWo && (HWo & 3) == 0) {
-        *reinterpret_cast<f32x4*>(dst) = f32x4{v[0], v[1], v[2], v[3]};
-      } else {
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (pp + r < HWo) dst[r] = v[r];
-      }
-    }
-  }
-}
-
 // ------------------------------------------------------- interleaved kernel ---
-// Same tiling as dcn_fwd_kernel, restructured so the matrix pipe never waits for a sampling
-// phase (PMC on the phase-separated kernel: MFMA busy 28 %, half of every wave's life spent
-// queued for the pipe because all waves reach their MFMA phase together).  The K loop body is
+// One workgroup (4 waves) = 64 consecutive output pixels x BN output channels; every lane owns one pixel and keeps
+// its 9 sampling recipes in registers.  The matrix pipe never waits for a sampling phase (a phase-separated
+// first version: MFMA busy 28 %, all waves reaching their MFMA phase together).  The K loop body is
 // one k-step = one tap:
 //     MFMAs of chunk i, k-step t, from LDS buffer A            (matrix pipe)
 //     sample tap t of chunk i+1 from registers -> LDS buffer B  (VALU + ds_write, in the
@@ -731,21 +548,6 @@ Plan make_plan(int B, int Cin, int Cout, int HWo) {
   return p;
 }
 
-template <int BN, int KC, int WPS>
-int launch(const DcnFwdArgs& a, hipStream_t st) {
-  constexpr int LD = KC * TAPS + LDPAD;
-  const size_t lds = (size_t)(BM + BN) * LD * sizeof(float);
-  dim3 grid((a.Ho * a.Wo + BM - 1) / BM, (a.Cout + BN - 1) / BN, a.B * a.splitk);
-  hipLaunchKernelGGL((dcn_fwd_kernel<BN, KC, WPS>), grid, dim3(256), lds, st, a);
-  if (a.splitk > 1) {
-    const long long n_per_b = (long long)a.Cout * a.Ho * a.Wo;
-    long long nb = ((long long)a.B * n_per_b + 255) / 256;
-    if (nb > 4096) nb = 4096;
-    hipLaunchKernelGGL(dcn_splitk_reduce_kernel, dim3((unsigned)nb), dim3(256), 0, st, a, n_per_b);
-  }
-  return cp_launch_status();
-}
-
 template <int BN, int WPS>
 int launch_pipe(const DcnFwdArgs& a, hipStream_t st) {
   const size_t lds = (size_t)2 * (BM + BN) * (4 * TAPS + LDPAD) * sizeof(float);
@@ -887,12 +689,6 @@ extern "C" int cp_dcn_v2_forward(const cp_dcn_shape* s, const float* x, const fl
     if (p.bn == 64) return launch_bf16x3<64, 2>(a, workspace, st);
     return launch_bf16x3<128, 2>(a, workspace, st);
   }
-  // A/B switch for timing runs (phase-separated kernel); read once per process, never on the call path
-  static const bool phased = getenv("CP_DCN_PHASED") != nullptr;
-  if (!phased) {                                  // interleaved kernel (default)
-    if (p.bn == 64) return launch_pipe<64, 3>(a, st);
-    if (p.bn == 128) return launch_pipe<128, 2>(a, st);
-  }
-  if (p.bn == 64) return launch<64, 4, 2>(a, st);
-  return launch<128, 4, 1>(a, st);
+  if (p.bn == 64) return launch_pipe<64, 3>(a, st);        // interleaved gather kernel, exact f32 MFMA
+  return launch_pipe<128, 2>(a, st);
 }

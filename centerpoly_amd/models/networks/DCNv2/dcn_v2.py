@@ -106,7 +106,7 @@ class _DCNv2Function(torch.autograd.Function):
         K = s.kh * s.kw
         Ho, Wo = om.shape[2], om.shape[3]
         grad_out = grad_out.contiguous()
-        gx = torch.zeros_like(x)
+        gx = torch.empty_like(x)                         # (overwritten: the library zero-fills it itself)
         gom = torch.empty_like(om)
         gw = torch.zeros_like(weight)
         gb = torch.zeros((s.Cout,), dtype=torch.float32, device=x.device)
@@ -120,7 +120,8 @@ class _DCNv2Function(torch.autograd.Function):
                                       bs, 1, _C.ptr(weight), _C.ptr(grad_out),
                                       _C.ptr(gx) if data else None, _C.ptr(gom) if data else None, bs,
                                       gmask_ptr if data else None, bs, _C.ptr(gw) if wgt else None,
-                                      _C.ptr(gb) if bias_ else None, _C.ptr(ws), ws.numel(), _C.stream())
+                                      _C.ptr(gb) if bias_ else None, DCN.backward_flags, _C.ptr(ws), ws.numel(),
+                                      _C.stream())
             _C.check(rc, "cp_dcn_v2_backward")
 
         timer = _C.kernel_timer
@@ -181,6 +182,9 @@ class DCN(nn.Module):
 
     # contraction of the TRAINING forward ("auto" | "f32" | "bf16x3"), a class-wide option (opt.dcn_contraction)
     train_contraction = "auto"
+    infer_contraction = "auto"  # default of forward_fused (prepare_inference(dcn_contraction=...) sets it per module)
+    # flags of cp_dcn_v2_backward (0 = split-bf16 x3; _C.DCN_BWD_EXACT_F32 = exact fp32 chain), class-wide as well
+    backward_flags = 0
 
     def __init__(self, in_channels, out_channels, kernel_size, stride, padding, dilation=1,
                  deformable_groups=1):
@@ -224,4 +228,4 @@ class DCN(nn.Module):
             om = cm(x)
         return dcn_v2_forward_raw(x.contiguous(), om.contiguous(), self.weight, None, self.stride,
                                   self.padding, self.dilation, self.deformable_groups, ep_scale,
-                                  ep_shift, relu, getattr(self, "contraction", "auto"), owner=self)
+                                  ep_shift, relu, getattr(self, "contraction", None) or DCN.infer_contraction, owner=self)

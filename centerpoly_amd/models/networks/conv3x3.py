@@ -8,16 +8,15 @@ products of split halves, and so does the weight gradient (cp_conv3x3_mfma_wgrad
 `conv_raw(conv, x)` is what every training call site uses for "conv without its bias";
 `conv3x3_infer(x, conv, w, bias, residual, relu)` is the inference call with the fused epilogue.
 Shapes the kernel does not take (stride 2, 1x1, 7x7, fewer than 24 input channels, tiny maps) go to the direct
-kernel or the library.  CP_CONV_MFMA=0 turns the kernel off (A/B measurements)."""
-import os
+kernel or the library.  `centerpoly_amd.arithmetic.configure("exact_f32")` turns the kernels off (library fp32)."""
 
 import torch
 import torch.nn.functional as F
 
 from ... import _C
 
-_ENABLED = os.environ.get("CP_CONV_MFMA", "1") != "0"
-_WGRAD = os.environ.get("CP_CONV_MFMA_WGRAD", "1") != "0"
+_ENABLED = True              # set by centerpoly_amd.arithmetic.configure
+_WGRAD = True
 MIN_CIN = 24                 # the contraction steps over 32 input channels: fewer would mostly multiply zeros
 MIN_WORKGROUPS = 128         # (of the narrowest tile form) below this the launch cannot fill the 256 CUs
 

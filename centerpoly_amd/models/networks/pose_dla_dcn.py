@@ -23,6 +23,10 @@ from .DCNv2.dcn_v2 import DCN, conv_bias
 from . import conv3x3
 from .conv3x3 import conv3x3_infer, conv_infer, conv_raw
 
+# A/B switches of this module (tools/probe_*.py set them; nothing reads the environment)
+HEADS_FUSED = True           # all heads of a stage as one kernel (cp_heads_fused_forward)
+CONV_DIRECT_WGRAD = True     # weight gradient of the full-resolution base layers from cp_conv_direct_wgrad
+
 BN_MOMENTUM = 0.1
 
 
@@ -95,7 +99,7 @@ class _DirectConvFn(torch.autograd.Function):
         x, weight = ctx.saved_tensors
         stride, pad = ctx.cfg
         go = go.contiguous()
-        direct_w = os.environ.get("CP_CONV_DIRECT_WGRAD", "1") != "0"
+        direct_w = CONV_DIRECT_WGRAD
         gx = gw = None
         if weight.shape[2] == 3 and stride == 1 and pad == 1 and conv3x3.mfma_enabled():
             # level0 (16 -> 16 at full resolution): the input gradient through the split-bf16 MFMA kernel (most of
@@ -613,7 +617,7 @@ def heads_fused_infer(owner, key, feat, w, b, tails, names):
     transposed [hc][co], 1x1 bias or None, hc, co).  The permuted weights are cached on `owner` under `key`.
     None when the shapes are not the kernel's (more than 4 heads, a head wider than 64 outputs, head_conv not a
     multiple of 64, input channels not a multiple of 32)."""
-    if os.environ.get("CP_HEADS_FUSED", "1") == "0" or not conv3x3.mfma_enabled():
+    if not HEADS_FUSED or not conv3x3.mfma_enabled():
         return None
     hcs = {t[2] for t in tails}
     B, cin, H, W = feat.shape
@@ -700,7 +704,7 @@ class DLASeg(nn.Module):
             if hasattr(m, "fold"):
                 m.fold()
             if isinstance(m, DCN):
-                m.contraction = dcn_contraction
+                m.contraction = None if dcn_contraction == "auto" else dcn_contraction   # None: DCN.infer_contraction
         self._heads_cat = None
         fcs = [getattr(self, h) for h in self.heads]
         if all(isinstance(fc, nn.Sequential) and len(fc) == 3 for fc in fcs):

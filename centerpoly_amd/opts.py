@@ -74,6 +74,9 @@ class opts(object):
         p.add_argument("--device_targets", action="store_true",
                        help="loader workers only pack the raw annotations; heat maps and regression "
                             "targets are built on the GPU (cp_polydet_targets) after the batch upload")
+        p.add_argument("--arithmetic", default="split_bf16", choices=["split_bf16", "exact_f32"],
+                       help="contraction arithmetic of the convolutions / heads / DCNv2 (centerpoly_amd/arithmetic.py): "
+                            "split-bf16 x3 on the bf16 matrix cores (default, ~2^-16 per product) or exact fp32 chains")
         p.add_argument("--no_reorder_flip", action="store_true")
         # sampler augmentation (reference: opts.py "train" group)
         p.add_argument("--not_rand_crop", action="store_true")
@@ -118,6 +121,8 @@ class opts(object):
     def parse(self, args=""):
         opt = self.parser.parse_args() if args == "" else self.parser.parse_args(args)
         opt.gpus_str = opt.gpus
+        from . import arithmetic
+        arithmetic.configure(opt.arithmetic)
         opt.gpus = [int(g) for g in opt.gpus.split(",")]
         opt.gpus = [i for i in range(len(opt.gpus))] if opt.gpus[0] >= 0 else [-1]
         opt.lr_step = [int(i) for i in opt.lr_step.split(",")]

@@ -48,7 +48,7 @@
 extern "C" {
 #endif
 
-#define CP_ABI_VERSION 1
+#define CP_ABI_VERSION 2
 
 enum {
   CP_OK = 0,
@@ -127,17 +127,23 @@ int cp_dcn_v2_forward(const cp_dcn_shape* s, const float* x, const float* offset
                       int32_t contraction, float* out, void* workspace, size_t workspace_bytes,
                       void* stream);
 
-/* Backward.  grad_* outputs may be NULL to skip that gradient.  grad_x,
- * grad_weight and grad_bias are ACCUMULATED INTO (caller zero-fills);
- * grad_offset / grad_mask are overwritten.  mask is the post-sigmoid mask
- * (mask_is_logit == 0) or the logits (then grad_mask is w.r.t. the logits). */
+/* Backward.  grad_* outputs may be NULL to skip that gradient.  grad_x, grad_offset and grad_mask are
+ * OVERWRITTEN (the library zero-fills grad_x itself before its kernels accumulate into it: uninitialised memory is
+ * fine, a caller that sums two branches adds them itself); grad_weight and grad_bias are ACCUMULATED INTO (caller
+ * zero-fills).  mask is the post-sigmoid mask (mask_is_logit == 0) or the logits (then grad_mask is w.r.t. the
+ * logits).  flags: 0 = the default kernels (split-bf16 x3 contraction, fp32 accumulate), or a bit-or of CP_DCN_BWD_*. */
+enum {
+  CP_DCN_BWD_EXACT_F32 = 1,     /* contract on the exact-fp32 MFMA chain instead of split-bf16 x3                 */
+  CP_DCN_BWD_NARROW_TILES = 2,  /* data gradients: 8-row tiles on every layer (A/B timing of the 12-row form)    */
+  CP_DCN_BWD_ROUND1_KERNELS = 4 /* the first-generation kernels (global float atomics; A/B timing and fallback)  */
+};
 size_t cp_dcn_v2_backward_workspace_bytes(const cp_dcn_shape* s);
 int cp_dcn_v2_backward(const cp_dcn_shape* s, const float* x, const float* offset,
                        int64_t offset_bstride, const float* mask, int64_t mask_bstride,
                        int32_t mask_is_logit, const float* weight, const float* grad_out,
                        float* grad_x, float* grad_offset, int64_t grad_offset_bstride,
                        float* grad_mask, int64_t grad_mask_bstride, float* grad_weight,
-                       float* grad_bias, void* workspace, size_t workspace_bytes, void* stream);
+                       float* grad_bias, int32_t flags, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------- depth-wise up-sampling --
  * IDAUp's `up` (depth-wise ConvTranspose2d, kernel 2f, stride f, padding f/2,

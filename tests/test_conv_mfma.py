@@ -220,9 +220,8 @@ def test_training_trajectory_matches_exact_arithmetic():
     import json, os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     runs = []
-    for extra in ({}, {"CP_CONV_MFMA": "0", "CP_DCN_BWD_F32": "1"}):
-        env = dict(os.environ, **extra)
-        out = subprocess.run([sys.executable, os.path.join(root, "tools", "train_trajectory.py"), "8"], env=env,
+    for arithmetic in ("split_bf16", "exact_f32"):
+        out = subprocess.run([sys.executable, os.path.join(root, "tools", "train_trajectory.py"), "8", arithmetic],
                              capture_output=True, text=True, timeout=600)
         assert out.returncode == 0, out.stderr[-2000:]
         runs.append(json.loads(out.stdout.strip().splitlines()[-1])["trajectory"])

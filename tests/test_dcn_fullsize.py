@@ -43,13 +43,13 @@ def _inputs(tag, B, Cin, Cout, H, W, off_std=0.5, clip=None):
     return x, om, w, go
 
 
-def _backward(x, om, w, go, want=("x", "om", "w", "b")):
+def _backward(x, om, w, go, want=("x", "om", "w", "b"), flags=0, gx_fill=float("nan")):
     """cp_dcn_v2_backward through the C ABI on the raw 27-channel offset/mask tensor (mask as logits)."""
     L = _C.lib()
     B, Cin, H, W = x.shape
     Cout = w.shape[0]
     s = _C.DcnShape(B, Cin, H, W, Cout, 3, 3, 1, 1, 1, 1)
-    gx = torch.zeros_like(x) if "x" in want else None
+    gx = torch.full_like(x, gx_fill) if "x" in want else None            # OVERWRITTEN, whatever it holds
     gom = torch.full_like(om, float("nan")) if "om" in want else None      # must be fully overwritten
     gw = torch.zeros_like(w) if "w" in want else None
     gb = torch.zeros(Cout, device=DEV) if "b" in want else None
@@ -60,7 +60,7 @@ def _backward(x, om, w, go, want=("x", "om", "w", "b")):
     rc = L.cp_dcn_v2_backward(s, _C.ptr(x), _C.ptr(om), bs, _C.c_void_p(om.data_ptr() + off_m), bs, 1, _C.ptr(w),
                               _C.ptr(go), _C.ptr(gx), _C.ptr(gom), bs,
                               _C.c_void_p(gom.data_ptr() + off_m) if gom is not None else None, bs, _C.ptr(gw),
-                              _C.ptr(gb), _C.ptr(ws), nws, _C.stream())
+                              _C.ptr(gb), flags, _C.ptr(ws), nws, _C.stream())
     _C.check(rc, "cp_dcn_v2_backward")
     torch.cuda.synchronize()
     return gx, gom, gw, gb

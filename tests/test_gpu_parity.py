@@ -590,6 +590,43 @@ def test_dcn_backward_vs_oracle_autograd(shape):
                                    err_msg="grad_" + name)
 
 
+@pytest.mark.parametrize("scale", [0.3, 6.0], ids=["window", "cold"])
+def test_dcn_backward_overwrites_grad_x_and_flags(scale):
+    """cp_dcn_v2_backward's contract: grad_x is OVERWRITTEN whatever it holds -- also when taps leave the staged
+    window and the cold path adds into it with float atomics (scale 6) -- and the exact-f32 / narrow-tile flags
+    compute the same gradients as the default split-bf16 kernels."""
+    L = _C.lib()
+    B, Cin, Cout, H, W = 2, 64, 64, 24, 40
+    x, om, w, b = _dcn_inputs("ovw", B, Cin, Cout, H, W, offset_scale=scale)
+    go = synth.normal("dcn/ovw/go", (B, Cout, H, W))
+    s = _C.DcnShape(B, Cin, H, W, Cout, 3, 3, 1, 1, 1, 1)
+    xg, omg, wg, gog = g(x), g(om), g(w), g(go)
+    bs, off_m = 27 * H * W, 4 * 18 * H * W
+    nws = L.cp_dcn_v2_backward_workspace_bytes(s)
+    ws = _C.workspace(nws, xg.device)
+
+    def run(flags, fill):
+        gx = torch.full_like(xg, fill)
+        gom = torch.full_like(omg, float("nan"))
+        rc = L.cp_dcn_v2_backward(s, _C.ptr(xg), _C.ptr(omg), bs, _C.c_void_p(omg.data_ptr() + off_m), bs, 1, _C.ptr(wg),
+                                  _C.ptr(gog), _C.ptr(gx), _C.ptr(gom), bs, _C.c_void_p(gom.data_ptr() + off_m), bs,
+                                  None, None, flags, _C.ptr(ws), nws, _C.stream())
+        _C.check(rc, "cp_dcn_v2_backward")
+        return gx.cpu(), gom.cpu()
+
+    base_x, base_om = run(0, 0.0)
+    assert torch.isfinite(base_x).all() and torch.isfinite(base_om).all()
+    for fill in (float("nan"), 123.0):
+        gx, gom = run(0, fill)
+        assert torch.equal(gx, base_x) and torch.equal(gom, base_om), fill     # deterministic and independent of the prefill
+    sx = base_x.abs().max().item()
+    for flags in (_C.DCN_BWD_EXACT_F32, _C.DCN_BWD_NARROW_TILES, _C.DCN_BWD_ROUND1_KERNELS):
+        gx, gom = run(flags, float("nan"))
+        np.testing.assert_allclose(gx.numpy(), base_x.numpy(), rtol=0, atol=2e-4 * sx, err_msg="flags %d" % flags)
+    assert L.cp_dcn_v2_backward(s, _C.ptr(xg), _C.ptr(omg), bs, _C.c_void_p(omg.data_ptr() + off_m), bs, 1, _C.ptr(wg),
+                                _C.ptr(gog), None, None, bs, None, bs, None, None, 64, _C.ptr(ws), nws, _C.stream()) == -1
+
+
 def test_dcn_backward_finite_difference():
     """Independent of the oracle: central differences on a scalar loss through the HIP forward."""
     from centerpoly_amd.models.networks.DCNv2.dcn_v2 import _DCNv2Function, dcn_v2_forward_raw
@@ -757,15 +794,18 @@ def _load_by_name(model, gold):
     return model.to(DEV).eval()
 
 
-@pytest.mark.parametrize("fused", [False, True, "bf16x3"], ids=["plain", "prepare_inference", "bf16x3"])
+@pytest.mark.parametrize("fused", [False, "f32", "bf16x3", "auto", "bf16x3_region"],
+                         ids=["plain", "prepare_inference", "bf16x3", "auto", "region"])
 def test_dla34_forward_vs_reference_golden(fused, golden):
     """Reference DLASeg wiring (with the oracle's DCN in the plugin slot) vs the HIP path, with and
-    without the inference fusions (folded BN, fused epilogues, concatenated heads)."""
+    without the inference fusions (folded BN, fused epilogues, concatenated heads), for every DCN contraction:
+    exact f32, split-bf16, "auto" (what bench.py and BaseDetector run) and the LDS-region kernel forced on every
+    DCN layer (what "auto" runs on the bench's large maps)."""
     from centerpoly_amd.models.model import create_model
     gold = golden("net_dla34")
     m = _load_by_name(create_model("dla_34", dict(cases.HEADS), 256), gold)
     if fused:
-        m.prepare_inference(dcn_contraction="bf16x3" if fused == "bf16x3" else "f32")
+        m.prepare_inference(dcn_contraction=fused)
     with torch.no_grad():
         out = m(g(cases.net_input("dla")))[0]
     for h in dict(cases.HEADS):

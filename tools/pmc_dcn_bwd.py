@@ -30,6 +30,6 @@ for i in range(n):
         rc = L.cp_dcn_v2_backward(s, P(x), P(om), bs, ctypes.c_void_p(om.data_ptr() + off_m), bs, 1, P(w), P(go),
                                   P(gx) if data else None, P(gom) if data else None, bs,
                                   ctypes.c_void_p(gom.data_ptr() + off_m) if data else None, bs,
-                                  None if data else P(gw), None, P(ws), ws_bytes, _C.stream())
+                                  None if data else P(gw), None, int(os.environ.get("PMC_BWD_FLAGS", "0")), P(ws), ws_bytes, _C.stream())
         assert rc == 0, rc
 torch.cuda.synchronize()

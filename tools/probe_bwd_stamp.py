@@ -26,7 +26,7 @@ nws = L.cp_dcn_v2_backward_workspace_bytes(s)
 ws = torch.zeros(nws, dtype=torch.uint8, device=dev)
 for _ in range(3):
     rc = L.cp_dcn_v2_backward(s, P(x), P(om), bs, ctypes.c_void_p(om.data_ptr() + off_m), bs, 1, P(w), P(go), P(gx),
-                              P(gom), bs, ctypes.c_void_p(gom.data_ptr() + off_m), bs, None, None, P(ws), nws,
+                              P(gom), bs, ctypes.c_void_p(gom.data_ptr() + off_m), bs, None, None, 0, P(ws), nws,
                               _C.stream())
     assert rc == 0
 torch.cuda.synchronize()

@@ -7,6 +7,7 @@ from centerpoly_amd import _C, synth
 
 L = _C.lib()
 dev = "cuda"
+FLAGS = int(os.environ.get("PROBE_BWD_FLAGS", "0"))      # bit-or of _C.DCN_BWD_* (1 exact f32, 2 narrow tiles, 4 round-1 kernels)
 
 
 def run(B, ci, co, H, W, what, n=20, off_scale=float(os.environ.get("PROBE_OFF_STD", "0.5"))):
@@ -26,7 +27,7 @@ def run(B, ci, co, H, W, what, n=20, off_scale=float(os.environ.get("PROBE_OFF_S
         rc = L.cp_dcn_v2_backward(s, P(x), P(om), bs, ctypes.c_void_p(om.data_ptr() + off_m), bs, 1, P(w), P(go),
                                   P(gx) if data else None, P(gom) if data else None, bs,
                                   ctypes.c_void_p(gom.data_ptr() + off_m) if data else None, bs,
-                                  P(gw) if weight else None, None, P(ws), nws, _C.stream())
+                                  P(gw) if weight else None, None, FLAGS, P(ws), nws, _C.stream())
         assert rc == 0, rc
     for _ in range(5):
         call()

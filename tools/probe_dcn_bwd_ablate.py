@@ -18,7 +18,7 @@ def run(ci, co, H, W, what, n=5, off_scale=0.5):
         rc = L.cp_dcn_v2_backward(s, P(x), P(om), bs, ctypes.c_void_p(om.data_ptr() + off_m), bs, 1, P(w), P(go),
                                   P(gx) if what != "weight" else None, P(gom) if what != "weight" else None, bs,
                                   ctypes.c_void_p(gom.data_ptr() + off_m) if what != "weight" else None, bs,
-                                  P(gw) if what != "data" else None, None, None, 0, _C.stream())
+                                  P(gw) if what != "data" else None, None, 0, None, 0, _C.stream())
         assert rc == 0, rc
     for _ in range(2): call()
     torch.cuda.synchronize()

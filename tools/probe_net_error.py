@@ -1,12 +1,14 @@
 """GPU probe: error of the DLA-34 network outputs against the golden outputs recorded from the reference's own
 modules (tests/golden/net_dla34.npz), per head, as a fraction of the head's max-norm, for the inference path
-(prepare_inference).  Run with CP_CONV_MFMA=0 for the library convolutions."""
+(prepare_inference).  `python tools/probe_net_error.py exact_f32` for the exact-fp32 arithmetic."""
 import json, os, sys
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "tests", "golden"))
 import numpy as np, torch
 import cases
 from centerpoly_amd.models.model import create_model
+from centerpoly_amd import arithmetic
+arithmetic.configure(sys.argv[1] if len(sys.argv) > 1 else "split_bf16")
 
 gold = dict(np.load(os.path.join(root, "tests", "golden", "net_dla34.npz"), allow_pickle=True))
 shapes = {k: tuple(v) for k, v in json.loads(str(gold["shapes"])).items()}

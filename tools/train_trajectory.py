@@ -1,6 +1,6 @@
 """Loss trajectory of a short DLA-34 + DCNv2 training run on synthetic data (GPU): prints one JSON line with the
-per-step loss terms.  Run twice -- default arithmetic and CP_CONV_MFMA=0 CP_DCN_BWD_F32=1 (library convolutions,
-exact-f32 DCN backward) -- to see that the split-bf16 kernels train the same model (tests/test_conv_mfma.py)."""
+per-step loss terms.  Run twice -- default arithmetic and `exact_f32` as second argument (library convolutions,
+exact-f32 DCN forward / backward) -- to see that the split-bf16 kernels train the same model (tests/test_conv_mfma.py)."""
 import contextlib, io, json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -13,7 +13,8 @@ from centerpoly_amd.trains.train_factory import train_factory
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 with contextlib.redirect_stdout(io.StringIO()):
     opt = opts().init(["polydet", "--arch", "dla_34", "--device_targets", "--input_h", "256", "--input_w", "512",
-                       "--batch_size", "2", "--num_iters", str(steps), "--poly_loss", "l1+iou", "--lr", "2.5e-4"])
+                       "--batch_size", "2", "--num_iters", str(steps), "--poly_loss", "l1+iou", "--lr", "2.5e-4",
+                       "--arithmetic", sys.argv[2] if len(sys.argv) > 2 else "split_bf16"])
     Dataset = get_dataset("synthetic", opt.task)
     opt = opts().update_dataset_info_and_set_heads(opt, Dataset)
     ds = Dataset(opt, "train")
