@@ -51,6 +51,7 @@ _SIGNATURES = {
     "cp_dcn_v2_backward_workspace_bytes": (c_size_t, [POINTER(DcnShape)]),
     "cp_dcn_v2_backward": (c_int32, [POINTER(DcnShape), _P, _P, c_int64, _P, c_int64, c_int32, _P, _P,
                                      _P, _P, c_int64, _P, c_int64, _P, _P, c_int32, _P, c_size_t, _P]),
+    "cp_upsample2x_add": (c_int32, [_P, _P, _P] + [c_int32] * 4 + [_P]),
     "cp_depthwise_up_forward": (c_int32, [_P, _P, _P, _P] + [c_int32] * 5 + [_P]),
     "cp_depthwise_up_backward": (c_int32, [_P, _P, _P, _P, _P] + [c_int32] * 5 + [_P]),
     "cp_bn_workspace_bytes": (c_size_t, [c_int32, c_int32, c_int64]),

@@ -79,8 +79,13 @@ struct CvArgs {
 // order (deterministic) and group 0 runs the epilogue.
 // S = 2: stride 2 (the first convolution of DLA levels 2-5): the staged tile is 2 TH + 1 rows x 65 columns, the B
 // fragments are read at twice the pixel stride (32-byte lane stride: two-way bank conflicts on those reads).
-template <int MT, int RW, int TAPS, int KS = 1, int S = 1>
+// ST = 2 with TAPS = 1 (the stride-2 1x1 skip convolutions of the Hourglass residuals, large_hourglass.py:55-81): a
+// 1x1 convolution of every second pixel -- the tile geometry is the stride-1 one, the staging reads at twice the
+// coordinates, nothing that is not multiplied is staged.
+template <int MT, int RW, int TAPS, int KS = 1, int ST = 1>
 __global__ __launch_bounds__(256 * KS, KS > 1 ? 4 : 2) void conv_mfma_kernel(CvArgs a) {
+  constexpr int S = TAPS == 1 ? 1 : ST;          // stride of the staged tile's geometry
+  constexpr int SUB = TAPS == 1 ? ST : 1;        // 1x1: input subsampling folded into the staging addresses
   constexpr int HALO = TAPS == 9 ? 1 : 0, LW = S * TW + (TAPS == 9 ? 3 : 1) - S;
   constexpr int TH = 4 * RW, LH = S * TH + (TAPS == 9 ? 3 : 1) - S, NT = 2 * RW, PLANE = 4 * LH * LW;   // fragments per half
   constexpr int UNITS = PLANE, ITERS = (UNITS + 255) / 256, SB = ITERS <= 6 ? ITERS : 5;
@@ -101,7 +106,7 @@ __global__ __launch_bounds__(256 * KS, KS > 1 ? 4 : 2) void conv_mfma_kernel(CvA
   for (int i = 0; i < ITERS; ++i) {
     const int u = tid + i * 256;
     const int col = u % LW, r = (u / LW) % LH, cg = u / (LW * LH);
-    const int gy = S * y0 - HALO + r, gx = S * x0 - HALO + col;
+    const int gy = SUB * (S * y0 - HALO + r), gx = SUB * (S * x0 - HALO + col);
     const bool ok = u < UNITS && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
     soff[i] = ok ? ((unsigned)(cg * 8) * (unsigned)HW + (unsigned)(gy * a.W + gx)) * 4u : OOB;
   }
@@ -300,7 +305,7 @@ int cp_conv_mfma_forward_strided(const float* const* xs, const int32_t* cs, int3
                                  int32_t Cout, int32_t taps, int32_t stride, int32_t relu, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   CP_CHECK_ARG(xs && cs && wperm && out && B >= 1 && nsrc >= 1 && nsrc <= MAXSRC && (taps == 1 || taps == 9));
-  if (stride != 1 && !(stride == 2 && taps == 9)) return CP_EUNSUPPORTED;
+  if (stride != 1 && stride != 2) return CP_EUNSUPPORTED;
   CvArgs a;
   int Cin = 0;
   for (int i = 0; i < MAXSRC; ++i) {
@@ -336,7 +341,12 @@ int cp_conv_mfma_forward_strided(const float* const* xs, const int32_t* cs, int3
     const int tiles = a.tiles_x * ((Ho + th - 1) / th);
     hipLaunchKernelGGL(kernel, dim3(tiles * a.ncot, B), dim3(256 * ks), 0, st, a);
   };
-  if (stride == 2) {                                 // 4-row tiles only (the staged tile is 9 x 65 pixels)
+  if (stride == 2 && taps == 1) {                    // 1x1 over every second pixel: the 1x1 forms on the output grid
+    if (Cout > 32 && wgs(4, 8) >= 448) launch(conv_mfma_kernel<4, 2, 1, 1, 2>, 4, 8, 1);
+    else if (wgs(2, 8) >= 320) launch(conv_mfma_kernel<2, 2, 1, 1, 2>, 2, 8, 1);
+    else if (wgs(2, 4) < 384 && a.nchunk >= 8) launch(conv_mfma_kernel<2, 1, 1, 4, 2>, 2, 4, 4);
+    else launch(conv_mfma_kernel<2, 1, 1, 1, 2>, 2, 4, 1);
+  } else if (stride == 2) {                          // 4-row tiles only (the staged tile is 9 x 65 pixels)
     if (Cout > 32 && wgs(4, 4) >= 448) launch(conv_mfma_kernel<4, 1, 9, 1, 2>, 4, 4, 1);
     else launch(conv_mfma_kernel<2, 1, 9, 1, 2>, 2, 4, 1);
   } else if (taps == 9) {

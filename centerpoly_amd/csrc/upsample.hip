@@ -293,6 +293,26 @@ __device__ __forceinline__ int argmax4(float a, float b, float c, float d) {    
   return k;                                           // (torch: val > max || isnan(val): the last NaN wins)
 }
 
+// out[b][c][y][x] = a[b][c][y][x] + low[b][c][y / 2][x / 2]: the Hourglass' `up1 + nn.Upsample(scale_factor=2)(low3)`
+// (large_hourglass.py kp_module.forward, reference :334-342) in one pass; one thread = 4 output pixels = 2 input pixels.
+__global__ __launch_bounds__(256) void up2_add_kernel(const float* __restrict__ a, const float* __restrict__ low,
+                                                      float* __restrict__ out, int H, int W, long long planes) {
+  const int q = blockIdx.x * 256 + threadIdx.x;       // float4 of the output row
+  const int y = blockIdx.y;
+  const long long pl = blockIdx.z;
+  const int W2 = 2 * W;
+  if (4 * q >= W2 || pl >= planes) return;
+  const float* lr = low + (pl * H + (y >> 1)) * W + 2 * q;
+  const long long o = (pl * 2 * H + y) * W2 + 4 * q;
+  if ((W & 1) == 0) {
+    const float2 l = *reinterpret_cast<const float2*>(lr);
+    const float4 v = *reinterpret_cast<const float4*>(a + o);
+    *reinterpret_cast<float4*>(out + o) = make_float4(v.x + l.x, v.y + l.x, v.z + l.y, v.w + l.y);
+  } else {
+    for (int e = 0; e < 4 && 4 * q + e < W2; ++e) out[o + e] = a[o + e] + lr[e >> 1];
+  }
+}
+
 __global__ __launch_bounds__(256) void maxpool2_fwd_kernel(const float* __restrict__ x, float* __restrict__ out, int H, int W,
                                                            int Ho, int Wo, long long planes) {
   const int q = blockIdx.x * 256 + threadIdx.x;       // pair of output pixels in the row
@@ -365,6 +385,16 @@ extern "C" int cp_maxpool2x2_forward(const float* x, float* out, int32_t B, int3
   if (planes > 65535 || Ho > 65535) return CP_EUNSUPPORTED;
   const dim3 grid(((Wo + 1) / 2 + 255) / 256, Ho, (unsigned)planes);
   hipLaunchKernelGGL(maxpool2_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, out, H, W, Ho, Wo, planes);
+  return cp_launch_status();
+}
+
+extern "C" int cp_upsample2x_add(const float* a, const float* low, float* out, int32_t B, int32_t C, int32_t H, int32_t W,
+                                 void* stream) {
+  CP_CHECK_ARG(a && low && out && B > 0 && C > 0 && H > 0 && W > 0);
+  const long long planes = (long long)B * C;
+  if (planes > 65535 || 2 * H > 65535) return CP_EUNSUPPORTED;
+  const dim3 grid(((2 * W + 3) / 4 + 255) / 256, 2 * H, (unsigned)planes);
+  hipLaunchKernelGGL(up2_add_kernel, grid, dim3(256), 0, (hipStream_t)stream, a, low, out, H, W, planes);
   return cp_launch_status();
 }
 

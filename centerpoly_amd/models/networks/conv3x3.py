@@ -81,7 +81,7 @@ def _launch(x, wp, bias, residual, cout, relu, taps=9, stride=1):
 
 
 def conv_infer(xs, owner, w, bias=None, residual=None, relu=False, conv=None, key="_mfma_wperm"):
-    """Inference: 3x3 / pad 1 (stride 1 or 2) or 1x1 (stride 1) convolution of the channel concatenation of `xs` -- read in place,
+    """Inference: 3x3 / pad 1 or 1x1 (stride 1 or 2) convolution of the channel concatenation of `xs` -- read in place,
     no torch.cat -- with the (folded) weight `w`, + bias + residual + ReLU in the kernel's epilogue.  The permuted
     weights are cached on `owner` (under `key`) for as long as `w` is the same, unmodified tensor.  `conv`, when
     given, is the module whose geometry must be the kernel's.  Returns None when the shape is not the kernel's."""
@@ -94,8 +94,6 @@ def conv_infer(xs, owner, w, bias=None, residual=None, relu=False, conv=None, ke
                 and conv.dilation == (1, 1) and conv.groups == 1 and conv.padding_mode == "zeros"):
             return None
         stride = conv.stride[0]
-        if stride == 2 and k != (3, 3):
-            return None
     x0 = xs[0]
     if not all(x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[0] == x0.shape[0]
                and x.shape[2:] == x0.shape[2:] for x in xs) or len(xs) > 4:

@@ -99,9 +99,32 @@ def make_hg_layer(k, dim0, dim1, mod, layer=residual, **kw):
     return _stack(layer(k, dim0, dim1, stride=2), dim1, mod)
 
 
+class _Up2Add(torch.autograd.Function):
+    """up1 + nearest x2 up-sampling of low in one kernel (cp_upsample2x_add); gradients: grad_out and its 2x2 sums."""
+
+    @staticmethod
+    def forward(ctx, up1, low):
+        B, C, H, W = low.shape
+        out = torch.empty_like(up1)
+        _C.check(_C.lib().cp_upsample2x_add(_C.ptr(up1), _C.ptr(low), _C.ptr(out), B, C, H, W, _C.stream()),
+                 "cp_upsample2x_add")
+        return out
+
+    @staticmethod
+    def backward(ctx, go):
+        return go, F.avg_pool2d(go, 2) * 4.0
+
+
 class MergeUp(nn.Module):
     def forward(self, up1, up2):
         return up1 + up2
+
+    def fused(self, up1, low):
+        """up1 + Upsample(x2)(low) without the up-sampled tensor."""
+        if up1.is_cuda and up1.dtype == torch.float32 and up1.is_contiguous() and low.is_contiguous() \
+                and up1.shape[2:] == (2 * low.shape[2], 2 * low.shape[3]) and up1.shape[0] * up1.shape[1] <= 65535:
+            return _Up2Add.apply(up1, low)
+        return None
 
 
 def make_kp_layer(cnv_dim, curr_dim, out_dim):
@@ -130,7 +153,8 @@ class kp_module(nn.Module):
     def forward(self, x):
         up1 = self.up1(x)
         low = self.low3(self.low2(self.low1(self.max1(x))))
-        return self.merge(up1, self.up2(low))
+        out = self.merge.fused(up1, low)
+        return out if out is not None else self.merge(up1, self.up2(low))
 
 
 class exkp(nn.Module):

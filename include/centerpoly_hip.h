@@ -165,6 +165,12 @@ int cp_maxpool2x2_forward(const float* x, float* out, int32_t B, int32_t C, int3
 int cp_maxpool2x2_backward(const float* x, const float* grad_out, float* grad_in, int32_t B, int32_t C, int32_t H,
                            int32_t W, void* stream);
 
+/* out = a + nearest-neighbour x2 up-sampling of low: `up1 + nn.Upsample(scale_factor=2)(low3)` of the Hourglass'
+ * kp_module (src/lib/models/networks/large_hourglass.py:334-342) in one pass.
+ * a, out [B][C][2H][2W]; low [B][C][H][W]; out may alias a. */
+int cp_upsample2x_add(const float* a, const float* low, float* out, int32_t B, int32_t C, int32_t H, int32_t W,
+                      void* stream);
+
 /* y <- act(y + bias[c] + residual) in place (fp32 NCHW, HW = H*W): the epilogue of a library
  * convolution whose BatchNorm was folded (inference).  bias / residual may be NULL. */
 int cp_bias_act_inplace(float* y, const float* bias, const float* residual, int32_t B, int32_t C,
@@ -220,7 +226,8 @@ int cp_conv_mfma_prepare(const float* weight, int32_t Cin, int32_t Cout, int32_t
 int cp_conv_mfma_forward(const float* const* xs, const int32_t* cs, int32_t nsrc, const void* wperm, const float* bias,
                          const float* residual, float* out, int32_t B, int32_t H, int32_t W, int32_t Cout,
                          int32_t taps, int32_t relu, void* stream);
-/* the same with a stride: 1, or 2 for the 3x3 form (the first convolution of DLA levels 2-5, pose_dla_dcn.py:38-46);
+/* the same with a stride of 1 or 2 (3x3: the first convolution of DLA levels 2-5, pose_dla_dcn.py:38-46, and of the
+ * Hourglass' down-sampling residuals; 1x1: their skip convolutions, large_hourglass.py:55-81);
  * out is [B][Cout][(H - 1) / stride + 1][(W - 1) / stride + 1] */
 int cp_conv_mfma_forward_strided(const float* const* xs, const int32_t* cs, int32_t nsrc, const void* wperm,
                                  const float* bias, const float* residual, float* out, int32_t B, int32_t H, int32_t W,

@@ -4,10 +4,13 @@ TEST INFRASTRUCTURE.
 Follows PolydetDataset.__getitem__ from the point where the annotations and the output affine
 are known (src/lib/datasets/sample/polydet.py:138-449) and the helpers it calls:
 gaussian_radius / gaussian2D / draw_umich_gaussian (src/lib/utils/image.py:95-141) and
-affine_transform (:62-65).  The helpers are pinned by tests/golden/targets_prims.npz (made by
-running the reference's own utils/image.py, tests/golden/gen_targets_golden.py); the object
-loop itself cannot be executed here (the dataset class needs cv2, pycocotools and the image
-files) and is restated from the source text.
+affine_transform (:62-65).  PINNED: the helpers by tests/golden/targets_prims.npz (made by
+running the reference's own utils/image.py, tests/golden/gen_targets_golden.py), the object
+loop by tests/golden/sampler_*.npz -- the reference's own PolydetDataset.__getitem__ run on its
+KITTIPolyStuff/BBoxes/val16.json annotations (tests/golden/gen_sampler_golden.py: blank-image
+stand-ins for the absent cv2, the targets do not depend on pixel values), seven cases incl.
+random crop / shift, mirroring with and without vertex re-ordering, polar and polar_fixed;
+tests/test_targets.py::test_object_loop_matches_reference_sampler holds every array bit-exact.
 
 Not restated (flags the accelerated path refuses): --elliptical_gt, --mse_loss, --dense_poly,
 --cat_spec_poly; `fg` (a warped instance image) is an input the loss never reads.

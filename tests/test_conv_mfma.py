@@ -304,8 +304,31 @@ def test_stride_2_forward(shape):
     _C.check(L.cp_conv_mfma_forward_strided(ptrs, chans, 1, P(wp), P(bias), P(res), P(out2), B, H, W, co, 9, 2, 1,
                                             _C.stream()), "forward")
     assert torch.equal(out, out2)                         # fixed order, no atomics: bit-identical reruns
-    assert L.cp_conv_mfma_forward_strided(ptrs, chans, 1, P(wp), None, None, P(out), B, H, W, co, 1, 2, 0,
-                                          _C.stream()) == -2      # stride 2 only in the 3x3 form
+    assert L.cp_conv_mfma_forward_strided(ptrs, chans, 1, P(wp), None, None, P(out), B, H, W, co, 9, 3, 0,
+                                          _C.stream()) == -2      # strides 1 and 2 only
+
+
+@pytest.mark.parametrize("shape", [(2, 32, 64, 40, 72), (1, 64, 128, 17, 33), (1, 128, 256, 256, 512), (1, 256, 384, 64, 128),
+                                   (1, 384, 384, 16, 32), (2, 384, 512, 8, 16), (1, 27, 40, 9, 131)],
+                         ids=["32->64", "odd map", "hourglass pre skip", "256->384", "384->384 small", "tiny map", "ragged"])
+def test_stride_2_pointwise_forward(shape):
+    """The stride-2 1x1 form (skip convolutions of the Hourglass' down-sampling residuals, large_hourglass.py:55-81):
+    a 1x1 convolution of every second pixel, with bias + residual + ReLU in the epilogue."""
+    B, ci, co, H, W = shape
+    L = _C.lib()
+    x, w = _t("p2x%s" % (shape,), (B, ci, H, W)), _t("p2w%s" % (shape,), (co, ci, 1, 1), 0.05)
+    bias = _t("p2b", (co,))
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    res = _t("p2r%s" % (shape,), (B, co, Ho, Wo))
+    wp = torch.empty(L.cp_conv_mfma_weight_bytes(ci, co, 1), dtype=torch.uint8, device=DEV)
+    _C.check(L.cp_conv_mfma_prepare(P(w), ci, co, 1, 0, P(wp), _C.stream()), "prepare")
+    out = torch.full((B, co, Ho, Wo), float("nan"), device=DEV)
+    ptrs, chans = (ctypes.c_void_p * 1)(x.data_ptr()), (ctypes.c_int32 * 1)(ci)
+    _C.check(L.cp_conv_mfma_forward_strided(ptrs, chans, 1, P(wp), P(bias), P(res), P(out), B, H, W, co, 1, 2, 1,
+                                            _C.stream()), "forward")
+    ref = F.relu(F.conv2d(x.double(), w.double(), bias.double(), stride=2) + res.double())
+    assert tuple(ref.shape) == tuple(out.shape)
+    assert torch.isfinite(out).all() and _rel(out, ref) <= TOL
 
 
 def test_stride_2_autograd_wrapper():

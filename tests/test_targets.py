@@ -186,3 +186,96 @@ def test_targets_edge_cases():
     assert out["reg_mask"][0].sum() == 0 and out["freq_mask"][0] == 1.0 and out["hm"][0].max() == 0.0
     assert out["reg_mask"][1].sum() <= M
     assert list(out["reg_mask"][2][1:4]) == [0, 0, 0]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The object loop against the REFERENCE's own PolydetDataset.__getitem__ (tests/golden/sampler_*.npz, made by
+# tests/golden/gen_sampler_golden.py running src/lib/datasets/sample/polydet.py:66-449 on KITTIPolyStuff/BBoxes/val16.json)
+SAMPLER_CASES = ["cart_crop", "cart_flip", "cart_shift", "cart_noreorder", "polar_flip", "polar_fixed", "cart_val"]
+CLASS_NAMES = ["person", "rider", "car", "truck", "bus", "train", "motorcycle", "bicycle"]
+
+
+def _border(border, size):
+    i = 1
+    while size - border // i <= border // i:
+        i *= 2
+    return border // i
+
+
+def _replay_draws(g, n):
+    """The sampler's random draws in the reference's order (sample/polydet.py:94-113): scale choice, centre x, centre y
+    (or the two shifts and the scale of --not_rand_crop), then the flip -- from the fixture's seed."""
+    H, W = [int(v) for v in g["img_hw"]]
+    np.random.seed(int(g["seed"]))
+    out = []
+    for _ in range(n):
+        c = np.array([W / 2., H / 2.], dtype=np.float32)
+        s = max(H, W) * 1.0
+        flipped = False
+        if str(g["split"]) == "train":
+            if not bool(g["not_rand_crop"]):
+                s = s * np.random.choice(np.arange(0.6, 1.4, 0.1))
+                wb, hb = _border(128, W), _border(128, H)
+                c[0] = np.random.randint(low=wb, high=W - wb)
+                c[1] = np.random.randint(low=hb, high=H - hb)
+            else:
+                sf, cf = float(g["scale"]), float(g["shift"])
+                c[0] += s * np.clip(np.random.randn() * cf, -2 * cf, 2 * cf)
+                c[1] += s * np.clip(np.random.randn() * cf, -2 * cf, 2 * cf)
+                s = s * np.clip(np.random.randn() * sf + 1, 1 - sf, 1 + sf)
+            if np.random.random() < float(g["flip_prob"]):
+                flipped = True
+                c[0] = W - c[0] - 1
+        out.append((c, s, flipped))
+    return out
+
+
+def _sampler_anns(g, j):
+    freq = g["class_freq"]
+    return [{"bbox": list(b), "poly": list(p), "cls_id": int(c) - 1, "pseudo_depth": float(d), "freq": float(freq[int(c) - 1])}
+            for b, p, c, d in zip(g["s%d_ann_bbox" % j], g["s%d_ann_poly" % j], g["s%d_ann_cat" % j], g["s%d_ann_depth" % j])]
+
+
+@pytest.mark.parametrize("case", SAMPLER_CASES)
+def test_object_loop_matches_reference_sampler(case, golden):
+    """oracle/targets.py::build_targets == the reference's own __getitem__, array for array, and the replayed draws
+    (what centerpoly_amd's host sampler mirrors) give the reference's centre and scale."""
+    g = golden("sampler_" + case)
+    n = len(g["img_ids"])
+    oh, ow = [int(v) for v in g["out_hw"]]
+    W = int(g["img_hw"][1])
+    for j, (c, s, flipped) in enumerate(_replay_draws(g, n)):
+        assert np.array_equal(c, g["s%d_c" % j]) and float(s) == float(g["s%d_s" % j]), (j, c, s)
+        t = opost.get_affine_transform(c, s, 0, [ow, oh])
+        r = otg.build_targets(_sampler_anns(g, j), t, flipped, W, oh, ow, 8, 128, 16, str(g["rep"]),
+                              no_reorder_flip=bool(g["no_reorder_flip"]))
+        for k in ("hm", "reg_mask", "ind", "poly", "pseudo_depth", "border_hm", "wh", "peak", "reg"):
+            assert np.array_equal(r[k], g["s%d_%s" % (j, k)]), (case, j, k)
+        assert float(r["freq_mask"]) == float(g["s%d_freq_mask" % j])
+        assert int(r["reg_mask"].sum()) > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", SAMPLER_CASES)
+def test_device_targets_match_reference_sampler(case, golden):
+    """cp_polydet_targets (csrc/targets.hip) against the arrays the reference's sampler produced: indices, masks and
+    heat maps bit-exact, float targets to 1 ulp of fp32 (the kernel's fp32 stores of float64 arithmetic)."""
+    from centerpoly_amd.datasets.sample.polydet import build_targets, collate, pack_annotations
+    g = golden("sampler_" + case)
+    n = len(g["img_ids"])
+    oh, ow = [int(v) for v in g["out_hw"]]
+    W = int(g["img_hw"][1])
+    packed = []
+    for j, (c, s, flipped) in enumerate(_replay_draws(g, n)):
+        t = opost.get_affine_transform(c, s, 0, [ow, oh])
+        packed.append(pack_annotations(_sampler_anns(g, j), t, flipped, W, 128, 16))
+    raw = {k: v.cuda() for k, v in collate(packed).items()}
+    out = build_targets(raw, oh, ow, 8, rep=str(g["rep"]), no_reorder_flip=bool(g["no_reorder_flip"]))
+    for j in range(n):
+        for k in ("reg_mask", "ind", "hm", "border_hm"):
+            assert np.array_equal(out[k][j].cpu().numpy(), g["s%d_%s" % (j, k)]), (case, j, k)
+        for k in ("poly", "pseudo_depth", "wh", "peak", "reg"):
+            ref = g["s%d_%s" % (j, k)]
+            np.testing.assert_allclose(out[k][j].cpu().numpy(), ref, rtol=2.4e-7, atol=1e-6 * max(1.0, np.abs(ref).max()),
+                                       err_msg="%s %d %s" % (case, j, k))
+        np.testing.assert_allclose(float(out["freq_mask"][j]), float(g["s%d_freq_mask" % j]), rtol=1e-6)

@@ -2,7 +2,7 @@
 # rocprofv3 kernel statistics of the B=4 training leg (bench.py --config 3 on one GPU).
 set -u
 cd "$(dirname "$0")/.."
-tag=${1:-r02}
+tag=${1:-r03}
 out=gpurun_out/prof_train_$tag
 mkdir -p $out
 export TMPDIR=/tmp
