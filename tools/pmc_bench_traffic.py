@@ -11,9 +11,10 @@ import csv, glob, json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 
-# (B, Cin, Cout, H, W) of the DLA-34 DCN layers at 2048x1024 by launch grid (threads): 256 threads per
-# 64-pixel tile; layers with Cout > 128 or under-filled grids use other grids and are not keyed here
-SHAPES = {524288: (1, 64, 64, 256, 512)}
+# (B, Cin, Cout, H, W) of the DLA-34 DCN layers at 2048x1024 by launch grid (threads).  Region kernel
+# (dcn_fwd_region.hip): 256 threads per 8 x 32 pixel tile and 64-channel block -> 64->64 @256x512 = 512 workgroups;
+# the gather kernels' 524288-thread grid (256 threads per 64-pixel tile) is kept for the exact-f32 arithmetic
+SHAPES = {131072: (1, 64, 64, 256, 512), 524288: (1, 64, 64, 256, 512)}
 
 
 # the fused heads' convolution of the same step (conv_mfma_kernel<4, 2, 9, 1>: 512 tiles x 16 output-channel tiles
@@ -41,9 +42,10 @@ for grid, shape in SHAPES.items():
 out = {"kernel_rev": bench.kernel_revision(), "inputs": "bench.py infer leg",
        "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE --output-format csv -- python3 bench.py "
                   "--config 2 --steps 3 --warmup 2 --no_cpu_baseline --no_train_point --no_detector_point "
-                  "--no_offset_points --no_other_configs (separate passes)",
-       "correction": "traffic = (2*FETCH_SIZE + WRITE_SIZE)*1024 bytes; the doubling is calibrated for wide coalesced "
-                     "streams, this kernel reads 8-byte gathers, so the read side is an upper bound",
+                  "--no_offset_points --no_other_configs --no_exact_point (separate passes)",
+       "correction": "traffic = (2*FETCH_SIZE + WRITE_SIZE)*1024 bytes (gfx950: FETCH_SIZE reports half of a wide coalesced "
+                     "stream's bytes; the region kernel stages rows with dword loads, 160-byte runs: the doubling is an "
+                     "upper bound for them)",
        "layers": layers, "_raw": raw}
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 print(json.dumps(out))

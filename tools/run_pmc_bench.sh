@@ -2,10 +2,11 @@
 # HBM-traffic PMC passes over bench.py's own inference leg (one counter per pass).
 set -u
 cd "$(dirname "$0")/.."
-out=gpurun_out/pmc_bench_${1:-r02}
+tag=${1:-r03}
+out=gpurun_out/pmc_bench_$tag
 mkdir -p $out
 export TMPDIR=/tmp
-B="python3 bench.py --config 2 --steps 3 --warmup 2 --no_cpu_baseline --no_train_point --no_detector_point --no_offset_points --no_other_configs"
+B="python3 bench.py --config 2 --steps 3 --warmup 2 --no_cpu_baseline --no_train_point --no_detector_point --no_offset_points --no_other_configs --no_exact_point"
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout -k 10 400 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out/$c -o $c -- $B > $out/$c.log 2>&1
   rc=$?; echo "pass $c rc=$rc"
@@ -14,7 +15,7 @@ done
 python3 tools/pmc_bench_traffic.py $out/FETCH_SIZE $out/WRITE_SIZE $out/dcn_fwd_pmc.json $out/conv_mfma_pmc.json $out/heads_fused_pmc.json
 for c in FETCH_SIZE WRITE_SIZE; do
   f=$(find $out/$c -name "*counter_collection.csv" | head -1)
-  (head -1 $f; grep dcn_fwd $f) > $out/r02_bench_dcn_fwd_pmc_$c.csv
-  (head -1 $f; grep "conv_mfma_kernel<4, 2, 9" $f) > $out/r02_bench_conv_mfma_pmc_$c.csv
-  (head -1 $f; grep "conv_heads_fused_kernel" $f) > $out/r02_bench_heads_fused_pmc_$c.csv
+  (head -1 $f; grep dcn_fwd $f) > $out/${tag}_bench_dcn_fwd_pmc_$c.csv
+  (head -1 $f; grep "conv_mfma_kernel<4, 2, 9" $f) > $out/${tag}_bench_conv_mfma_pmc_$c.csv
+  (head -1 $f; grep "conv_heads_fused_kernel" $f) > $out/${tag}_bench_heads_fused_pmc_$c.csv
 done
