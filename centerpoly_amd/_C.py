@@ -48,6 +48,10 @@ _SIGNATURES = {
     "cp_dcn_v2_forward_kernel": (c_int32, [POINTER(DcnShape), c_int32]),
     "cp_dcn_v2_forward": (c_int32, [POINTER(DcnShape), _P, _P, c_int64, _P, c_int64, c_int32, _P, _P,
                                     _P, _P, c_int32, c_int32, _P, _P, c_size_t, _P]),
+    "cp_dcn_v2_forward_fused_supported": (c_int32, [POINTER(DcnShape)]),
+    "cp_dcn_v2_forward_fused_workspace_bytes": (c_size_t, [POINTER(DcnShape)]),
+    "cp_dcn_v2_forward_fused": (c_int32, [POINTER(DcnShape), _P, _P, _P, _P, _P, _P, _P, c_int32, c_int32, _P, _P, _P,
+                                          c_size_t, _P]),
     "cp_dcn_v2_backward_workspace_bytes": (c_size_t, [POINTER(DcnShape)]),
     "cp_dcn_v2_backward": (c_int32, [POINTER(DcnShape), _P, _P, c_int64, _P, c_int64, c_int32, _P, _P,
                                      _P, _P, c_int64, _P, c_int64, _P, _P, c_int32, _P, c_size_t, _P]),

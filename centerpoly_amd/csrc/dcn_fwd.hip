@@ -657,7 +657,7 @@ extern "C" int cp_dcn_v2_forward(const cp_dcn_shape* s, const float* x, const fl
       if (rc != CP_OK) return rc;
     }
     return cp_dcn_region_forward(s, x, offset, offset_bstride, mask, mask_bstride, mask_is_logit, workspace, bias,
-                                 ep_scale, ep_shift, relu, out, st);
+                                 ep_scale, ep_shift, relu, out, nullptr, nullptr, nullptr, st);
   }
   if (p.splitk > 1 || bf) {
     if (!workspace || workspace_bytes < cp_dcn_v2_forward_workspace_bytes(s)) return CP_EWORKSPACE;
@@ -691,4 +691,36 @@ extern "C" int cp_dcn_v2_forward(const cp_dcn_shape* s, const float* x, const fl
   }
   if (p.bn == 64) return launch_pipe<64, 3>(a, st);        // interleaved gather kernel, exact f32 MFMA
   return launch_pipe<128, 2>(a, st);
+}
+
+// --------------------------------------------------------------------------------------------------------------------
+// DCN with its conv_offset_mask inside the kernel (dcn_fwd_region.hip, template FUSE).
+static size_t fused_region_bytes(const cp_dcn_shape* s) { return cp_align_up(cp_dcn_region_wperm_bytes(s), 256); }
+
+extern "C" int cp_dcn_v2_forward_fused_supported(const cp_dcn_shape* s) {
+  return s && s->B > 0 && s->Cout > 0 && cp_dcn_region_supported(s) && region_pays(s) ? 1 : 0;
+}
+
+extern "C" size_t cp_dcn_v2_forward_fused_workspace_bytes(const cp_dcn_shape* s) {
+  if (!cp_dcn_v2_forward_fused_supported(s)) return 0;
+  return fused_region_bytes(s) + cp_align_up(cp_dcn_region_om_wperm_bytes(s), 256);
+}
+
+extern "C" int cp_dcn_v2_forward_fused(const cp_dcn_shape* s, const float* x, const float* om_weight, const float* om_bias,
+                                       const float* weight, const float* bias, const float* ep_scale,
+                                       const float* ep_shift, int32_t relu, int32_t prepared, float* om_out, float* out,
+                                       void* workspace, size_t workspace_bytes, void* stream) {
+  CP_CHECK_ARG(s && x && om_weight && om_bias && weight && out);
+  if (!cp_dcn_v2_forward_fused_supported(s)) return CP_EUNSUPPORTED;
+  if (!workspace || workspace_bytes < cp_dcn_v2_forward_fused_workspace_bytes(s)) return CP_EWORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  void* om_wp = (char*)workspace + fused_region_bytes(s);
+  if (!prepared) {
+    int rc = cp_dcn_region_prepare(s, weight, workspace, st);
+    if (rc != CP_OK) return rc;
+    rc = cp_dcn_region_prepare_om(s, om_weight, om_wp, st);
+    if (rc != CP_OK) return rc;
+  }
+  return cp_dcn_region_forward(s, x, nullptr, 0, nullptr, 0, 1, workspace, bias, ep_scale, ep_shift, relu, out, om_wp, om_bias,
+                               om_out, st);
 }

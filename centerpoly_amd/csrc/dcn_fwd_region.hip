@@ -75,6 +75,11 @@ struct RegionArgs {
   int B, Cin, H, W, Cout;
   int mask_is_logit, relu;
   int tiles_x, tiles_y;
+  // fused conv_offset_mask (kernel template FUSE): its weights in fragment order, its bias, optional copy-out of the
+  // 27 channels it computes ([B][27][H][W]: the training backward reads them)
+  const bf16x8* om_wp;
+  const float* om_bias;
+  float* om_out;
 };
 
 // wp[(((cb * nchunk + chunk) * 9 + t) * 4 + ct * 2 + hl) * 64 + lane][j] =
@@ -96,6 +101,29 @@ __global__ __launch_bounds__(256) void dcn_region_wperm_kernel(const float* __re
   for (int j = 0; j < 8; ++j) {
     const int ci = chunk * 16 + 8 * (lane >> 5) + j;
     const float v = (co < Cout && ci < Cin) ? w[((long long)co * Cin + ci) * TAPS + t] : 0.f;
+    const __bf16 h = (__bf16)v;
+    o[j] = hl ? (__bf16)(v - (float)h) : h;
+  }
+  wp[e] = o;
+}
+
+// conv_offset_mask weights [27][Cin][3][3] -> A fragments (32 rows, rows >= 27 zero):
+// wp[((chunk * 9 + t) * 2 + hl) * 64 + lane][j] = half hl of Wom[co = lane & 31][ci = 16 chunk + 8 (lane >> 5) + j][t]
+__global__ __launch_bounds__(256) void dcn_region_omperm_kernel(const float* __restrict__ w, bf16x8* __restrict__ wp, int Cin,
+                                                                int total) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= total) return;
+  const int lane = e & 63;
+  int r = e >> 6;
+  const int hl = r & 1;
+  r >>= 1;
+  const int t = r % TAPS, chunk = r / TAPS;
+  const int co = lane & 31;
+  bf16x8 o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int ci = chunk * 16 + 8 * (lane >> 5) + j;
+    const float v = (co < 27 && ci < Cin) ? w[((long long)co * Cin + ci) * TAPS + t] : 0.f;
     const __bf16 h = (__bf16)v;
     o[j] = hl ? (__bf16)(v - (float)h) : h;
   }
@@ -129,6 +157,13 @@ __device__ __forceinline__ void bcast_rows(unsigned u, unsigned& r0, unsigned& r
   asm("" : "+v"(r0), "+v"(r1));
 }
 
+// FUSE: the 27-channel conv_offset_mask (3x3, pad 1, + bias; DCNv2/dcn_v2.py's `self.conv_offset_mask(x)`, reference call
+// site pose_dla_dcn.py:354) is computed HERE for the workgroup's own tile, as a first pass over the input chunks on the
+// same matrix cores (split-bf16 x3, the arithmetic of conv_mfma.hip), instead of by a separate launch whose 27-channel
+// output is written to and read back from memory: the tile +-1 halo is staged pre-split (bf16 hi | lo, 8 channels =
+// one B fragment per cell), 9 taps x 2 rows x 3 MFMAs per 16-channel chunk, the result lands in accumulator registers,
+// one v_permlane32_swap per register hands every lane half its row's 27 values, and the recipes are built from them.
+template <bool FUSE>
 __global__ __launch_bounds__(256, 2) void dcn_fwd_region_kernel(RegionArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -165,7 +200,7 @@ __global__ __launch_bounds__(256, 2) void dcn_fwd_region_kernel(RegionArgs a) {
   // ------------------------------------------------------------------ sampling recipes
   // Lane half h computes and KEEPS the 9 recipes of row 2w + h of its pixel column (both halves of a lane pair need
   // the recipe of the row being processed: it is broadcast per tap with one v_permlane32_swap per value, below):
-  //   u0 = (1 - ly) * mask, u1 = ly * mask, lx, region byte offset.   u0 = -0.0f marks a cold sample (weights 0).
+  //   u0 = (1 - ly) * mask, u1 = ly * mask, lx, region byte offset (bit 31: cold sample, a global pixel index).
   float ru0[TAPS], ru1[TAPS], rlx[TAPS];
   unsigned roff[TAPS];                    // first (y0 + 1) << 16 | (x0 + 1), later the region byte offset
   unsigned bb_lo = 0xFFFFFFFFu, bb_hi = 0u;
@@ -174,11 +209,111 @@ __global__ __launch_bounds__(256, 2) void dcn_fwd_region_kernel(RegionArgs a) {
     const bool ok = y < H && x < W;
     const unsigned vo = ok ? (unsigned)(y * W + x) * 4u : OOB;
     float oy[TAPS], ox[TAPS], ml[TAPS];
+    if constexpr (FUSE) {
+      // ---- conv_offset_mask of this tile: pre-split staging tile [buffer][hi | lo][lane half][10 x 34 cells] x 16 B
+      constexpr int OW = TW + 2, OCELLS = (TH + 2) * OW, OPL = OCELLS * 16, OBUF = 4 * OPL;     // 340 cells, 21 760 B
+      constexpr int OITEMS = (2 * OCELLS + 255) / 256;                                              // (cell, half) per thread: 3
+      static_assert(2 * OBUF <= 2 * CHB - 64, "staging tiles of the offset convolution fit below the bounding-box words");
+      unsigned ovo[OITEMS], olds[OITEMS];
 #pragma unroll
-    for (int t = 0; t < TAPS; ++t) {
-      oy[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_off, vo, (unsigned)(2 * t) * plane_bytes, 0));
-      ox[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_off, vo, (unsigned)(2 * t + 1) * plane_bytes, 0));
-      ml[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_msk, vo, (unsigned)t * plane_bytes, 0));
+      for (int i = 0; i < OITEMS; ++i) {
+        const int e = tid + 256 * i;
+        const int hf = e / OCELLS, cell = e - hf * OCELLS;
+        const int ry = cell / OW, rx = cell - ry * OW;
+        const int gy = ty - 1 + ry, gx = tx - 1 + rx;
+        const bool in = e < 2 * OCELLS && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+        ovo[i] = in ? ((unsigned)(hf * 8) * (unsigned)HW + (unsigned)(gy * W + gx)) * 4u : OOB;
+        olds[i] = e < 2 * OCELLS ? (unsigned)(hf * OPL + cell * 16) : 0xFFFFFFFFu;
+      }
+      auto ostage = [&](int i, int c0, unsigned buf) __attribute__((always_inline)) {
+        if (olds[i] == 0xFFFFFFFFu) return;
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          v[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_x, ovo[i], (unsigned)(c0 + j) * plane_bytes, 0));
+        unsigned hi[4], lo[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) split2(v[2 * j], v[2 * j + 1], hi[j], lo[j]);
+        *reinterpret_cast<u32x4*>(smem + buf + olds[i]) = u32x4{hi[0], hi[1], hi[2], hi[3]};
+        *reinterpret_cast<u32x4*>(smem + buf + 2 * OPL + olds[i]) = u32x4{lo[0], lo[1], lo[2], lo[3]};
+      };
+      f32x16 aom[2];
+#pragma unroll
+      for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) aom[r][i] = 0.f;
+      const bf16x8* oq = a.om_wp + lane;
+      bf16x8 of[2] = {oq[0], oq[64]};
+#pragma unroll
+      for (int i = 0; i < OITEMS; ++i) ostage(i, 0, 0u);
+      __syncthreads();
+      const unsigned obase = (unsigned)kg * OPL + (unsigned)((2 * wid) * OW + px) * 16u;
+      for (int c = 0; c < nchunk; ++c) {
+        const unsigned cur = (unsigned)(c & 1) * OBUF, nxt = OBUF - cur;
+        const bool more = c + 1 < nchunk;
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t) {
+          const int ky = t / 3, kx = t - ky * 3;
+          bf16x8 on[2];
+          {
+            const int nt = (t + 1 < TAPS) ? c * TAPS + t + 1 : (more ? (c + 1) * TAPS : c * TAPS);
+            on[0] = oq[(long long)nt * 128];
+            on[1] = oq[(long long)nt * 128 + 64];
+          }
+          if (more && t % 3 == 0 && t / 3 < OITEMS) ostage(t / 3, (c + 1) * 16, nxt);
+#pragma unroll
+          for (int r = 0; r < 2; ++r) {
+            const unsigned ad = cur + obase + (unsigned)(((r + ky) * OW + kx) * 16);
+            const bf16x8 bh = *reinterpret_cast<const bf16x8*>(smem + ad);
+            const bf16x8 bl = *reinterpret_cast<const bf16x8*>(smem + ad + 2 * OPL);
+            aom[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(of[0], bh, aom[r], 0, 0, 0);
+            aom[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(of[0], bl, aom[r], 0, 0, 0);
+            aom[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(of[1], bh, aom[r], 0, 0, 0);
+          }
+          of[0] = on[0];
+          of[1] = on[1];
+        }
+        __syncthreads();                      // next chunk's tile written, this one no longer read
+      }
+      // + bias (this lane's channels: (i & 3) + 8 (i >> 2) + 4 kg), then one swap per register: the lower lane half
+      // ends up with all 32 rows of tile row 2w, the upper half with those of row 2w + 1 --
+      //   channel co of this lane's row = (co >> 2) & 1 ? qv[i] : pv[i],  i = (co & 3) + 4 (co >> 3)
+      const __amdgpu_buffer_rsrc_t rs_ob = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.om_bias), 0, 27 * 4, 0x00020000);
+      float pv[16], qv[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const float bv = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                                       rs_ob, (unsigned)kg * 16u + (unsigned)((i & 3) + 8 * (i >> 2)) * 4u, 0, 0));
+        unsigned p0 = __builtin_bit_cast(unsigned, aom[0][i] + bv), q0 = __builtin_bit_cast(unsigned, aom[1][i] + bv);
+        const auto sw = __builtin_amdgcn_permlane32_swap(p0, q0, false, false);
+        p0 = sw[0];
+        q0 = sw[1];
+        asm("" : "+v"(p0), "+v"(q0));
+        pv[i] = __builtin_bit_cast(float, p0);
+        qv[i] = __builtin_bit_cast(float, q0);
+      }
+      auto chan = [&](int co) __attribute__((always_inline)) -> float {
+        const int i = (co & 3) + 4 * (co >> 3);
+        return ((co >> 2) & 1) ? qv[i] : pv[i];
+      };
+#pragma unroll
+      for (int t = 0; t < TAPS; ++t) {
+        oy[t] = chan(2 * t);
+        ox[t] = chan(2 * t + 1);
+        ml[t] = chan(18 + t);
+      }
+      if (a.om_out && ok) {                   // the training backward reads the 27 channels
+        float* oo = a.om_out + (long long)b * 27 * HW + (long long)y * W + x;
+#pragma unroll
+        for (int co = 0; co < 27; ++co) oo[(long long)co * HW] = chan(co);
+      }
+    } else {
+#pragma unroll
+      for (int t = 0; t < TAPS; ++t) {
+        oy[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_off, vo, (unsigned)(2 * t) * plane_bytes, 0));
+        ox[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_off, vo, (unsigned)(2 * t + 1) * plane_bytes, 0));
+        ml[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_msk, vo, (unsigned)t * plane_bytes, 0));
+      }
     }
 #pragma unroll
     for (int t = 0; t < TAPS; ++t) {
@@ -230,29 +365,47 @@ __global__ __launch_bounds__(256, 2) void dcn_fwd_region_kernel(RegionArgs a) {
     ox0 = (spanx > 0 && spanx <= RW) ? xmin - ((RW - spanx) >> 1) : tx - 4;  //                         |dx| < 3
   }
 
-  // recipes -> region byte offsets.  Samples outside the window are cold, in two classes:
-  //   * all four corners inside the image (the common case): the weights stay, the offset register holds
-  //     0x80000000 | (y0 W + x0) and the step gathers the corners from memory with them;
-  //   * touching the image border: weights zeroed (u0 = -0.0f is the flag), the step rebuilds the sample from the
-  //     offset tensor with per-corner bounds (rare: a one-pixel frame around the image).
+  // recipes -> region byte offsets.  Samples outside the window are cold: the offset register holds
+  // 0x80000000 | (y0' W + x0') and the step gathers the 2 x 2 corners from memory with the recipe's weights.  A cold
+  // sample touching the image border (one row or column of its corners outside: zero there, DCNv2's per-corner rule)
+  // is re-expressed on the in-image 2 x 2 block next to it: the row / column weight that survives moves into u0 / u1,
+  // lx becomes 0 or 1 -- same value, no bounds checks and no second code path in the K loop.
   unsigned long long coldany[TAPS];       // per wave and tap: low word = lanes of row 0, high word = row 1
 #pragma unroll
   for (int t = 0; t < TAPS; ++t) {
     const unsigned pk = roff[t];
-    const int y0 = (int)(pk >> 16) - 1, x0 = (int)(pk & 0xffffu) - 1;
+    int y0 = (int)(pk >> 16) - 1, x0 = (int)(pk & 0xffffu) - 1;
     const int iy = y0 - oy0, ix = x0 - ox0;
     const bool live = pk != 0xFFFFFFFFu;
     const bool warm = (unsigned)iy <= (unsigned)(RH - 2) && (unsigned)ix <= (unsigned)(RW - 2);
     const bool cold = live && !warm;
-    const bool interior = y0 >= 0 && x0 >= 0 && y0 + 1 < H && x0 + 1 < W;
     roff[t] = (live && warm) ? (unsigned)(iy * RW + ix) * 16u : 0u;
     if (cold) {
-      if (interior) {
-        roff[t] = 0x80000000u | (unsigned)(y0 * W + x0);
-      } else {
-        ru0[t] = -0.f;
-        ru1[t] = 0.f;
+      float u0 = ru0[t], u1 = ru1[t], lx = rlx[t];
+      if (y0 < 0) {                         // rows (-1, 0) -> (0, 1): the weight of row 0 moves up
+        u0 = u1;
+        u1 = 0.f;
+        y0 = 0;
+      } else if (y0 + 1 >= H) {             // rows (H - 1, H) -> (H - 2, H - 1)
+        u1 = u0;
+        u0 = 0.f;
+        y0 = H - 2;
       }
+      if (x0 < 0) {                         // columns (-1, 0) -> (0, 1)
+        u0 *= lx;
+        u1 *= lx;
+        lx = 0.f;
+        x0 = 0;
+      } else if (x0 + 1 >= W) {             // columns (W - 1, W) -> (W - 2, W - 1)
+        u0 *= 1.f - lx;
+        u1 *= 1.f - lx;
+        lx = 1.f;
+        x0 = W - 2;
+      }
+      ru0[t] = u0;
+      ru1[t] = u1;
+      rlx[t] = lx;
+      roff[t] = 0x80000000u | (unsigned)(y0 * W + x0);
     }
     coldany[t] = __builtin_amdgcn_ballot_w64(cold);
   }
@@ -305,30 +458,6 @@ __global__ __launch_bounds__(256, 2) void dcn_fwd_region_kernel(RegionArgs a) {
   for (int f = 0; f < 4; ++f) wf[f] = wq[f * 64];
   __syncthreads();
   RSTAMP(3);
-
-  // cold path: the flagged lane pair of (row r, tap t) rebuilds its sample from the offset tensor and gathers
-  auto cold_fix = [&](int r, int t, int cbase, float (&v)[8]) __attribute__((always_inline)) {
-    const int y = ty + 2 * wid + r, x = tx + px;
-    const unsigned vo = (unsigned)(y * W + x) * 4u;
-    const float oyv = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_off, vo, (unsigned)(2 * t) * plane_bytes, 0));
-    const float oxv = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_off, vo, (unsigned)(2 * t + 1) * plane_bytes, 0));
-    float m = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_msk, vo, (unsigned)t * plane_bytes, 0));
-    if (a.mask_is_logit) m = 1.f / (1.f + __expf(-m));
-    const int ky = t / 3, kx = t - ky * 3;
-    const float py = (float)(y - 1 + ky) + oyv, pxf = (float)(x - 1 + kx) + oxv;
-    const float fy = floorf(py), fx = floorf(pxf);
-    const int y0 = (int)fy, x0 = (int)fx;
-    const float ly = py - fy, lx = pxf - fx, hx = 1.f - lx;
-    const float u0 = (1.f - ly) * m, u1 = ly * m;
-    const bool y0ok = y0 >= 0, y1ok = y0 + 1 < H, x0ok = x0 >= 0, x1ok = x0 + 1 < W;
-    const float w00 = (y0ok && x0ok) ? u0 * hx : 0.f, w01 = (y0ok && x1ok) ? u0 * lx : 0.f;
-    const float w10 = (y1ok && x0ok) ? u1 * hx : 0.f, w11 = (y1ok && x1ok) ? u1 * lx : 0.f;
-    const int ya = max(y0, 0), yb = min(y0 + 1, H - 1), xa = max(x0, 0), xc = min(x0 + 1, W - 1);
-    const float* p = xb + (long long)cbase * HW;
-#pragma unroll
-    for (int j = 0; j < 8; ++j, p += HW)
-      v[j] = w00 * p[ya * W + xa] + w01 * p[ya * W + xc] + w10 * p[yb * W + xa] + w11 * p[yb * W + xc];
-  };
 
   const unsigned kgoff = (unsigned)kg * (2u * PLANE);
   for (int c = 0; c < nchunk; ++c) {
@@ -393,7 +522,7 @@ __global__ __launch_bounds__(256, 2) void dcn_fwd_region_kernel(RegionArgs a) {
           }
         }
         if (__builtin_expect((unsigned)(coldany[t] >> (32 * r)) != 0u, 0)) {
-          if ((int)bof[r] < 0) {            // interior cold sample: same weights, corners gathered from memory
+          if ((int)bof[r] < 0) {            // cold sample: same weights, corners gathered from memory
             const float* p = xb + (long long)(c * 16 + kg * 8) * HW + (bof[r] & 0x7fffffffu);
             float g[8][4];
 #pragma unroll
@@ -406,7 +535,6 @@ __global__ __launch_bounds__(256, 2) void dcn_fwd_region_kernel(RegionArgs a) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] = w00 * g[j][0] + w01 * g[j][1] + w10 * g[j][2] + w11 * g[j][3];
           }
-          if (bu0[r] == 0x80000000u) cold_fix(r, t, c * 16 + kg * 8, v);
         }
         unsigned hi[4], lo[4];
 #pragma unroll
@@ -515,7 +643,7 @@ bool cp_dcn_region_supported(const cp_dcn_shape* s) {
   if (s->kh != 3 || s->kw != 3 || s->stride != 1 || s->pad != 1 || s->dil != 1 || s->deformable_groups != 1) return false;
   if (s->Cin < 16 || (s->Cin & 15)) return false;
   const long long HW = (long long)s->H * s->W;
-  if (s->H >= 65534 || s->W >= 65534) return false;
+  if (s->H >= 65534 || s->W >= 65534 || s->H < 2 || s->W < 2) return false;
   if (HW * 4 * 27 >= (1ll << 31) || (long long)s->Cin * HW * 4 >= (1ll << 31)) return false;
   if (s->B > 65535 || (s->Cout + 63) / 64 > 65535) return false;
   return true;
@@ -532,10 +660,20 @@ int cp_dcn_region_prepare(const cp_dcn_shape* s, const float* weight, void* wp, 
   return cp_launch_status();
 }
 
+size_t cp_dcn_region_om_wperm_bytes(const cp_dcn_shape* s) { return (size_t)(s->Cin / 16) * TAPS * 2 * 64 * 16; }
+
+int cp_dcn_region_prepare_om(const cp_dcn_shape* s, const float* om_weight, void* wp, hipStream_t st) {
+  const int total = (int)(cp_dcn_region_om_wperm_bytes(s) / 16);
+  hipLaunchKernelGGL(dcn_region_omperm_kernel, dim3((total + 255) / 256), dim3(256), 0, st, om_weight, (bf16x8*)wp, s->Cin, total);
+  return cp_launch_status();
+}
+
+// om_wp != null: the fused form (conv_offset_mask computed in the kernel from om_wp / om_bias; offset / mask unused,
+// om_out optional)
 int cp_dcn_region_forward(const cp_dcn_shape* s, const float* x, const float* offset, int64_t offset_bstride,
                           const float* mask, int64_t mask_bstride, int32_t mask_is_logit, const void* wp,
                           const float* bias, const float* ep_scale, const float* ep_shift, int32_t relu, float* out,
-                          hipStream_t st) {
+                          const void* om_wp, const float* om_bias, float* om_out, hipStream_t st) {
   RegionArgs a;
   a.x = x; a.offset = offset; a.mask = mask; a.wp = (const bf16x8*)wp; a.bias = bias;
   a.ep_scale = ep_scale; a.ep_shift = ep_shift; a.out = out;
@@ -544,11 +682,16 @@ int cp_dcn_region_forward(const cp_dcn_shape* s, const float* x, const float* of
   a.mask_is_logit = mask_is_logit; a.relu = relu;
   a.tiles_x = (s->W + TW - 1) / TW;
   a.tiles_y = (s->H + TH - 1) / TH;
+  a.om_wp = (const bf16x8*)om_wp; a.om_bias = om_bias; a.om_out = om_out;
   const int lds = 2 * CHB;
-  static const hipError_t attr = hipFuncSetAttribute((const void*)dcn_fwd_region_kernel,
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-  (void)attr;
   dim3 grid(a.tiles_x * a.tiles_y, (s->Cout + 63) / 64, s->B);
-  hipLaunchKernelGGL(dcn_fwd_region_kernel, grid, dim3(256), lds, st, a);
+  if (om_wp) {
+    a.mask_is_logit = 1;                    // the convolution's mask channels are logits
+    (void)hipFuncSetAttribute((const void*)dcn_fwd_region_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipLaunchKernelGGL(dcn_fwd_region_kernel<true>, grid, dim3(256), lds, st, a);
+  } else {
+    (void)hipFuncSetAttribute((const void*)dcn_fwd_region_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipLaunchKernelGGL(dcn_fwd_region_kernel<false>, grid, dim3(256), lds, st, a);
+  }
   return cp_launch_status();
 }

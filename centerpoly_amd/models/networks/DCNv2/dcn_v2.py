@@ -85,6 +85,41 @@ def dcn_v2_forward_raw(x, om, weight, bias, stride=1, pad=1, dil=1, dg=1, ep_sca
     return out
 
 
+def dcn_v2_module_forward(x, om_weight, om_bias, weight, bias, ep_scale=None, ep_shift=None, relu=False, owner=None,
+                          want_om=False):
+    """The whole DCN module in one launch (cp_dcn_v2_forward_fused): conv_offset_mask computed inside the DCN kernel.
+    Returns (out, om or None), or None where the library does not run its region kernel for this shape (the caller
+    then runs the convolution and dcn_v2_forward_raw).  `owner` keeps the workspace with both permuted weight sets."""
+    L = _C.lib()
+    s = _shape(x, weight, 1, 1, 1, 1)
+    if tuple(weight.shape[2:]) != (3, 3) or tuple(om_weight.shape) != (27, s.Cin, 3, 3) \
+            or not L.cp_dcn_v2_forward_fused_supported(s):
+        return None
+    nws = L.cp_dcn_v2_forward_fused_workspace_bytes(s)
+    prepared, ws = 0, None
+    if owner is not None:
+        key = (weight._version, weight.data_ptr(), om_weight._version, om_weight.data_ptr(), str(weight.device), tuple(x.shape))
+        cache = owner.__dict__.get("_dcn_fused_ws")
+        if cache is not None and cache[0] is weight and cache[1] is om_weight and cache[2] == key:
+            ws, prepared = cache[3], 1
+        else:
+            ws = _C.workspace(nws, x.device)
+            owner.__dict__["_dcn_fused_ws"] = (weight, om_weight, key, ws)
+    else:
+        ws = _C.workspace(nws, x.device)
+    out = torch.empty((s.B, s.Cout, s.H, s.W), dtype=torch.float32, device=x.device)
+    om = torch.empty((s.B, 27, s.H, s.W), dtype=torch.float32, device=x.device) if want_om else None
+    timer = _C.kernel_timer
+    end = timer.start(("dcn_fwd", s.Cin, s.Cout, s.H, s.W, s.B)) if timer is not None else None
+    rc = L.cp_dcn_v2_forward_fused(s, _C.ptr(x), _C.ptr(om_weight), _C.ptr(om_bias), _C.ptr(weight), _C.ptr(bias),
+                                   _C.ptr(ep_scale), _C.ptr(ep_shift), 1 if relu else 0, prepared, _C.ptr(om), _C.ptr(out),
+                                   _C.ptr(ws), nws, _C.stream())
+    if end is not None:
+        end.record()
+    _C.check(rc, "cp_dcn_v2_forward_fused")
+    return out, om
+
+
 class _DCNv2Function(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, om, weight, bias, stride, pad, dil, dg):
@@ -185,6 +220,8 @@ class DCN(nn.Module):
     infer_contraction = "auto"  # default of forward_fused (prepare_inference(dcn_contraction=...) sets it per module)
     # flags of cp_dcn_v2_backward (0 = split-bf16 x3; _C.DCN_BWD_EXACT_F32 = exact fp32 chain), class-wide as well
     backward_flags = 0
+    # conv_offset_mask inside the DCN kernel where the library's region kernel runs (cp_dcn_v2_forward_fused)
+    fuse_offset_conv = True
 
     def __init__(self, in_channels, out_channels, kernel_size, stride, padding, dilation=1,
                  deformable_groups=1):
@@ -223,6 +260,13 @@ class DCN(nn.Module):
         """Inference: DCN + per-channel affine (folded BatchNorm, bias included) + ReLU
         in the kernel's epilogue (replaces DeformConv.forward's three passes)."""
         cm = self.conv_offset_mask
+        con = getattr(self, "contraction", None) or DCN.infer_contraction
+        if DCN.fuse_offset_conv and con in ("auto", "bf16x3") and x.is_cuda and x.dtype == torch.float32 \
+                and self.stride == 1 and self.padding == 1 and self.dilation == 1 and self.deformable_groups == 1:
+            r = dcn_v2_module_forward(x.contiguous(), cm.weight, cm.bias, self.weight, None, ep_scale, ep_shift, relu,
+                                      owner=self)
+            if r is not None:
+                return r[0]
         om = conv3x3_infer(x, cm, cm.weight, cm.bias, conv=cm)      # split-bf16 MFMA kernel, bias in its epilogue
         if om is None:
             om = cm(x)

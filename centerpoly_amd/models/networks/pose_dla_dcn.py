@@ -753,7 +753,7 @@ class DLASeg(nn.Module):
             for m in self.modules():
                 if hasattr(m, "_folded"):
                     m._folded = None
-                for k in [k for k in m.__dict__ if k.startswith(("_mfma_wperm", "_heads_wperm", "_heads_fused", "_dcn_fwd_ws"))]:
+                for k in [k for k in m.__dict__ if k.startswith(("_mfma_wperm", "_heads_wperm", "_heads_fused", "_dcn_fwd_ws", "_dcn_fused_ws"))]:
                     del m.__dict__[k]          # permuted inference weights / DCN workspaces of the folded tensors
             self._heads_cat = None
         return super().train(mode)

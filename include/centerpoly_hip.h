@@ -127,6 +127,24 @@ int cp_dcn_v2_forward(const cp_dcn_shape* s, const float* x, const float* offset
                       int32_t contraction, float* out, void* workspace, size_t workspace_bytes,
                       void* stream);
 
+/* The DCN module of the reference in ONE launch: `DCN.forward` (upstream DCNv2/dcn_v2.py: out = conv_offset_mask(x);
+ * o1, o2, mask = chunk(out, 3); offset = cat(o1, o2); mask = sigmoid(mask); dcn_v2_conv(x, offset, mask, ...)), i.e.
+ * cp_dcn_v2_forward with the 27-channel 3x3 / pad 1 convolution that produces its offsets and mask logits computed
+ * inside the kernel for each tile (split-bf16 x3 like cp_conv3x3_mfma_forward) instead of by a launch of its own.
+ *   om_weight [27][Cin][3][3], om_bias [27]: conv_offset_mask's parameters
+ *   om_out    NULL, or [B][27][H][W]: receives the convolution's output (what cp_dcn_v2_backward needs as
+ *             offset = om_out, mask = om_out + 18 H W, both batch strides 27 H W, mask_is_logit = 1)
+ *   prepared  != 0: `workspace` still holds the permuted weights of an earlier call with the same two weight tensors
+ * Only where the LDS-region kernel runs (cp_dcn_v2_forward_fused_supported: 3x3, stride 1, pad 1, dilation 1,
+ * Cin % 16 == 0, enough tiles to fill the chip); CP_EUNSUPPORTED otherwise -- run the convolution and
+ * cp_dcn_v2_forward then. */
+int cp_dcn_v2_forward_fused_supported(const cp_dcn_shape* s);
+size_t cp_dcn_v2_forward_fused_workspace_bytes(const cp_dcn_shape* s);
+int cp_dcn_v2_forward_fused(const cp_dcn_shape* s, const float* x, const float* om_weight, const float* om_bias,
+                            const float* weight, const float* bias, const float* ep_scale, const float* ep_shift,
+                            int32_t relu, int32_t prepared, float* om_out, float* out, void* workspace,
+                            size_t workspace_bytes, void* stream);
+
 /* Backward.  grad_* outputs may be NULL to skip that gradient.  grad_x, grad_offset and grad_mask are
  * OVERWRITTEN (the library zero-fills grad_x itself before its kernels accumulate into it: uninitialised memory is
  * fine, a caller that sums two branches adds them itself); grad_weight and grad_bias are ACCUMULATED INTO (caller

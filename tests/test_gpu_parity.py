@@ -413,6 +413,37 @@ def test_dcn_forward_region_kernel(shape, scale):
     np.testing.assert_allclose(out.numpy(), ref.numpy(), rtol=1e-3, atol=1e-4 * s_)
 
 
+@pytest.mark.parametrize("shape,om_scale", [((1, 64, 64, 64, 512), 0.02), ((2, 32, 40, 70, 250), 0.05), ((1, 128, 128, 64, 256), 0.15),
+                                            ((1, 16, 64, 128, 256), 0.4)],
+                         ids=["64->64", "ragged", "128->128", "large offsets"])
+def test_dcn_module_fused_offset_conv(shape, om_scale):
+    """cp_dcn_v2_forward_fused: the DCN module (conv_offset_mask -> chunk / sigmoid -> deformable convolution) in one
+    launch, against conv2d in float64 + the oracle's DCN on the same inputs; its copy-out of the 27 offset / mask
+    channels against the convolution.  om_scale sets the size of the offsets the convolution produces (0.02: a tenth
+    of a pixel; 0.4: several pixels, most samples through the cold gathers, image borders included)."""
+    from centerpoly_amd.models.networks.DCNv2.dcn_v2 import dcn_v2_module_forward
+    B, Cin, Cout, H, W = shape
+    x, _, w, b = _dcn_inputs("fused%dx%d" % (Cin, Cout), *shape)
+    wom = synth.normal("dcn/fused/wom%d" % Cin, (27, Cin, 3, 3), 0.0, om_scale)
+    bom = synth.normal("dcn/fused/bom", (27,), 0.0, 0.3)
+    om_ref = torch.nn.functional.conv2d(T(x).double(), T(wom).double(), T(bom).double(), padding=1).float()
+    ref = _dcn_ref(x, om_ref.numpy(), w, b)
+    r = dcn_v2_module_forward(g(x), g(wom), g(bom), g(w), g(b), want_om=True)
+    assert r is not None
+    out, om = r[0].cpu(), r[1].cpu()
+    so = om_ref.abs().max().item()
+    np.testing.assert_allclose(om.numpy(), om_ref.numpy(), rtol=0, atol=3e-5 * so)
+    s_ = ref.abs().max().item()
+    err = (out - ref).abs().max().item() / s_
+    assert err < 2e-4, err
+    # fused BN + ReLU epilogue and no copy-out: the same values through the other code path
+    sc, sh = g(synth.uniform("dcn/fused/sc", (Cout,), 0.5, 1.5)), g(synth.normal("dcn/fused/sh", (Cout,)))
+    r2 = dcn_v2_module_forward(g(x), g(wom), g(bom), g(w), None, ep_scale=sc, ep_shift=sh, relu=True)
+    exp = torch.relu((r[0] - g(b).view(1, -1, 1, 1)) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))
+    torch.testing.assert_close(r2[0], exp, rtol=1e-5, atol=1e-5 * s_)
+    assert r2[1] is None
+
+
 def test_dcn_large_offsets_and_borders():
     """Offsets that throw samples far outside the image (zero contribution) and exactly
     onto integer / border positions."""
