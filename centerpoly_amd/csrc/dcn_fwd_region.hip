@@ -225,12 +225,13 @@ __global__ __launch_bounds__(256, 2) void dcn_fwd_region_kernel(RegionArgs a) {
         ovo[i] = in ? ((unsigned)(hf * 8) * (unsigned)HW + (unsigned)(gy * W + gx)) * 4u : OOB;
         olds[i] = e < 2 * OCELLS ? (unsigned)(hf * OPL + cell * 16) : 0xFFFFFFFFu;
       }
-      auto ostage = [&](int i, int c0, unsigned buf) __attribute__((always_inline)) {
-        if (olds[i] == 0xFFFFFFFFu) return;
-        float v[8];
+      auto oload = [&](int i, int c0, float (&v)[8]) __attribute__((always_inline)) {
 #pragma unroll
         for (int j = 0; j < 8; ++j)
           v[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_x, ovo[i], (unsigned)(c0 + j) * plane_bytes, 0));
+      };
+      auto owrite = [&](int i, unsigned buf, const float (&v)[8]) __attribute__((always_inline)) {
+        if (olds[i] == 0xFFFFFFFFu) return;
         unsigned hi[4], lo[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) split2(v[2 * j], v[2 * j + 1], hi[j], lo[j]);
@@ -244,34 +245,58 @@ __global__ __launch_bounds__(256, 2) void dcn_fwd_region_kernel(RegionArgs a) {
         for (int i = 0; i < 16; ++i) aom[r][i] = 0.f;
       const bf16x8* oq = a.om_wp + lane;
       bf16x8 of[2] = {oq[0], oq[64]};
+      {
+        float v0[OITEMS][8];
 #pragma unroll
-      for (int i = 0; i < OITEMS; ++i) ostage(i, 0, 0u);
+        for (int i = 0; i < OITEMS; ++i) oload(i, 0, v0[i]);
+#pragma unroll
+        for (int i = 0; i < OITEMS; ++i) owrite(i, 0u, v0[i]);
+      }
       __syncthreads();
       const unsigned obase = (unsigned)kg * OPL + (unsigned)((2 * wid) * OW + px) * 16u;
       for (int c = 0; c < nchunk; ++c) {
         const unsigned cur = (unsigned)(c & 1) * OBUF, nxt = OBUF - cur;
         const bool more = c + 1 < nchunk;
+        float sv[8];                          // next chunk's tile: item t / 3 is loaded at tap 3 i and written at tap 3 i + 2
+        // B fragments (hi, lo) of both rows for one tap, read one tap ahead of the MFMAs that use them
+        auto bfrag = [&](int t, bf16x8 (&f)[2][2]) __attribute__((always_inline)) {
+          const int ky = t / 3, kx = t - ky * 3;
+#pragma unroll
+          for (int r = 0; r < 2; ++r) {
+            const unsigned ad = cur + obase + (unsigned)(((r + ky) * OW + kx) * 16);
+            f[r][0] = *reinterpret_cast<const bf16x8*>(smem + ad);
+            f[r][1] = *reinterpret_cast<const bf16x8*>(smem + ad + 2 * OPL);
+          }
+        };
+        bf16x8 bc[2][2];
+        bfrag(0, bc);
 #pragma unroll
         for (int t = 0; t < TAPS; ++t) {
-          const int ky = t / 3, kx = t - ky * 3;
-          bf16x8 on[2];
+          bf16x8 on[2], bn[2][2];
           {
             const int nt = (t + 1 < TAPS) ? c * TAPS + t + 1 : (more ? (c + 1) * TAPS : c * TAPS);
             on[0] = oq[(long long)nt * 128];
             on[1] = oq[(long long)nt * 128 + 64];
           }
-          if (more && t % 3 == 0 && t / 3 < OITEMS) ostage(t / 3, (c + 1) * 16, nxt);
+          if (t + 1 < TAPS) bfrag(t + 1, bn);
+          static_assert(OITEMS <= 3, "three staging slots per chunk");
+          if (more && t % 3 == 0 && t / 3 < OITEMS) oload(t / 3, (c + 1) * 16, sv);
+          if (more && t % 3 == 2 && t / 3 < OITEMS) owrite(t / 3, nxt, sv);
 #pragma unroll
           for (int r = 0; r < 2; ++r) {
-            const unsigned ad = cur + obase + (unsigned)(((r + ky) * OW + kx) * 16);
-            const bf16x8 bh = *reinterpret_cast<const bf16x8*>(smem + ad);
-            const bf16x8 bl = *reinterpret_cast<const bf16x8*>(smem + ad + 2 * OPL);
-            aom[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(of[0], bh, aom[r], 0, 0, 0);
-            aom[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(of[0], bl, aom[r], 0, 0, 0);
-            aom[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(of[1], bh, aom[r], 0, 0, 0);
+            aom[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(of[0], bc[r][0], aom[r], 0, 0, 0);
+            aom[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(of[0], bc[r][1], aom[r], 0, 0, 0);
+            aom[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(of[1], bc[r][0], aom[r], 0, 0, 0);
           }
           of[0] = on[0];
           of[1] = on[1];
+          if (t + 1 < TAPS) {
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+              bc[r][0] = bn[r][0];
+              bc[r][1] = bn[r][1];
+            }
+          }
         }
         __syncthreads();                      // next chunk's tile written, this one no longer read
       }
