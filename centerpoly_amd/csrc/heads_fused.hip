@@ -230,6 +230,177 @@ __global__ __launch_bounds__(256, 2) void conv_heads_fused_kernel(HeadsArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Input-resident form (Cin <= 96: the whole (8 + 2) x (32 + 2) halo tile of every input channel fits in LDS as bf16
+// hi | lo, 43.5 KB per 32 channels).  The form above re-stages -- loads, splits, stores -- the same input tile for each
+// of a head's HC / 64 channel tiles, and the heads of a pixel tile sit in different workgroups on different XCDs: the
+// PMC passes showed ~1 GB fetched for a 34 MB input.  Here one workgroup = 8 waves = (pixel tile, TWO heads): the tile
+// is staged ONCE by all 512 threads, then waves 0-3 run head 2 i and waves 4-7 head 2 i + 1 over it, each through its
+// channel tiles, with no further barrier (8 waves per CU as before, one staging instead of eight).
+template <int MT2>
+__global__ __launch_bounds__(512, 2) void conv_heads_fused_res_kernel(HeadsArgs a) {
+  extern __shared__ __attribute__((aligned(16))) bf16x8 Xd[];          // [chunk][hi | lo][PLANE]
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = (tid >> 6) & 3, g = lane >> 4, c = lane & 15;
+  const int hsel = __builtin_amdgcn_readfirstlane(tid >> 8);
+  const int npair = (a.nheads + 1) / 2;
+  const int head = 2 * (blockIdx.x % npair) + hsel, tile = blockIdx.x / npair;
+  const int x0 = (tile % a.tiles_x) * TW, y0 = (tile / a.tiles_x) * TH, b = blockIdx.y;
+  const int HW = a.H * a.W;
+  const int ncl = a.HC / 64, KS2 = a.HC / 32;
+
+  {
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.x + (long long)b * a.Cin * HW), 0, (int)((unsigned)a.Cin * (unsigned)HW * 4u), 0x00020000);
+    const unsigned cstep = (unsigned)HW * 4u;
+    constexpr int IT = (UNITS + 511) / 512;
+    for (int chunk = 0; chunk < a.nchunk; ++chunk) {
+      float v[IT][8];
+#pragma unroll
+      for (int i = 0; i < IT; ++i) {
+        const int u = tid + i * 512;
+        const int col = u % LW, r = (u / LW) % LH, cg = u / (LW * LH);
+        const int gy = y0 - 1 + r, gx = x0 - 1 + col;
+        const bool ok = u < UNITS && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+        const unsigned o = ok ? ((unsigned)(chunk * KC + cg * 8) * (unsigned)HW + (unsigned)(gy * a.W + gx)) * 4u : OOB;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          v[i][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_x, o == OOB ? OOB : o + j * cstep, 0, 0));
+      }
+#pragma unroll
+      for (int i = 0; i < IT; ++i) {
+        const int u = tid + i * 512;
+        if (u < UNITS) {
+          bf16x8 h, l;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const __bf16 hh = (__bf16)v[i][j];
+            h[j] = hh;
+            l[j] = (__bf16)(v[i][j] - (float)hh);
+          }
+          Xd[chunk * 2 * PLANE + u] = h;
+          Xd[chunk * 2 * PLANE + PLANE + u] = l;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (head >= a.nheads) return;                                        // odd number of heads: the last pair's second half
+
+  const long long tstride = (long long)a.nchunk * 9 * 2 * 64;
+  const int bbase = (g * LH + wid * RW) * LW + c;
+  const bf16x8* wq2 = a.wp2[head] + lane;
+
+  f32x4 acc2[MT2][NT];
+#pragma unroll
+  for (int m2 = 0; m2 < MT2; ++m2)
+#pragma unroll
+    for (int n = 0; n < NT; ++n) acc2[m2][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  for (int cl = 0; cl < ncl; ++cl) {
+    const int cot = head * ncl + cl;
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const bf16x8* wq = a.wp1 + (long long)cot * MT * tstride + lane;
+    bf16x8 af[MT][2];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      af[m][0] = wq[m * tstride];
+      af[m][1] = wq[m * tstride + 64];
+    }
+    for (int chunk = 0; chunk < a.nchunk; ++chunk) {
+      const bf16x8* Xs = Xd + chunk * 2 * PLANE;
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const int dy = tap / 3, dx = tap % 3;
+        bf16x8 an[MT][2];
+        {
+          const bool last = tap == 8 && chunk == a.nchunk - 1;
+          const bf16x8* nq = wq + (long long)((chunk * 9 + tap + (last ? 0 : 1)) * 2) * 64;
+#pragma unroll
+          for (int m = 0; m < MT; ++m) {
+            an[m][0] = nq[m * tstride];
+            an[m][1] = nq[m * tstride + 64];
+          }
+        }
+        bf16x8 bh[NT], bl[NT];
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+          const int idx = bbase + ((n >> 1) + dy) * LW + (n & 1) * 16 + dx;
+          bh[n] = Xs[idx];
+          bl[n] = Xs[PLANE + idx];
+        }
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int n = 0; n < NT; ++n) {
+            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[m][0], bh[n], acc[m][n], 0, 0, 0);
+            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[m][0], bl[n], acc[m][n], 0, 0, 0);
+            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[m][1], bh[n], acc[m][n], 0, 0, 0);
+          }
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+          af[m][0] = an[m][0];
+          af[m][1] = an[m][1];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    const float* b1p = a.b1 + cot * 64 + 4 * g;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      float bia[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) bia[j] = b1p[16 * (2 * p + (j >> 2)) + (j & 3)];
+      bf16x8 a2h[MT2], a2l[MT2];
+#pragma unroll
+      for (int m2 = 0; m2 < MT2; ++m2) {
+        const bf16x8* q = wq2 + (long long)(((m2 * KS2 + 2 * cl + p) * 2) * 64);
+        a2h[m2] = q[0];
+        a2l[m2] = q[64];
+      }
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        bf16x8 fh, fl;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float v = fmaxf(acc[2 * p + (j >> 2)][n][j & 3] + bia[j], 0.f);
+          const __bf16 h = (__bf16)v;
+          fh[j] = h;
+          fl[j] = (__bf16)(v - (float)h);
+        }
+#pragma unroll
+        for (int m2 = 0; m2 < MT2; ++m2) {
+          acc2[m2][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2h[m2], fh, acc2[m2][n], 0, 0, 0);
+          acc2[m2][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2h[m2], fl, acc2[m2][n], 0, 0, 0);
+          acc2[m2][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2l[m2], fh, acc2[m2][n], 0, 0, 0);
+        }
+      }
+    }
+  }
+
+  const int co_n = a.cout[head];
+  float* ob = a.out[head] + (long long)b * co_n * HW;
+  const float* b2 = a.b2[head];
+#pragma unroll
+  for (int m2 = 0; m2 < MT2; ++m2) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int cls = 16 * m2 + 4 * g + r;
+      if (cls >= co_n) continue;
+      const float bv = b2 ? b2[cls] : 0.f;
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        const int y = y0 + wid * RW + (n >> 1), x = x0 + (n & 1) * 16 + c;
+        if (y < a.H && x < a.W) ob[(long long)cls * HW + (long long)y * a.W + x] = acc2[m2][n][r] + bv;
+      }
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -279,7 +450,17 @@ int cp_heads_fused_forward(const float* x, const void* wperm1, const float* b1, 
   const int tiles = a.tiles_x * ((H + TH - 1) / TH);
   int widest = 0;
   for (int h = 0; h < nheads; ++h) widest = cout[h] > widest ? cout[h] : widest;
-  if (widest <= 32)
+  const size_t res_lds = (size_t)a.nchunk * 2 * PLANE * sizeof(bf16x8);          // input-resident form: Cin <= 96
+  if (res_lds <= 160 * 1024 - 1024 && nheads >= 2) {
+    const int npair = (nheads + 1) / 2;
+    if (widest <= 32) {
+      (void)hipFuncSetAttribute((const void*)conv_heads_fused_res_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)res_lds);
+      hipLaunchKernelGGL(conv_heads_fused_res_kernel<2>, dim3(tiles * npair, B), dim3(512), res_lds, (hipStream_t)stream, a);
+    } else {
+      (void)hipFuncSetAttribute((const void*)conv_heads_fused_res_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)res_lds);
+      hipLaunchKernelGGL(conv_heads_fused_res_kernel<4>, dim3(tiles * npair, B), dim3(512), res_lds, (hipStream_t)stream, a);
+    }
+  } else if (widest <= 32)
     hipLaunchKernelGGL(conv_heads_fused_kernel<2>, dim3(tiles * nheads, B), dim3(256), 0, (hipStream_t)stream, a);
   else
     hipLaunchKernelGGL(conv_heads_fused_kernel<4>, dim3(tiles * nheads, B), dim3(256), 0, (hipStream_t)stream, a);
