@@ -3,7 +3,7 @@
 # --kernel-trace).  Usage: tools/run_pmc_bwd.sh <tag>   -> gpurun_out/pmc_bwd_<tag>/<pass>/...
 set -u
 cd "$(dirname "$0")/.."
-tag=${1:-r02}
+tag=${1:-r03}
 out=gpurun_out/pmc_bwd_$tag
 mkdir -p $out
 export TMPDIR=/tmp
