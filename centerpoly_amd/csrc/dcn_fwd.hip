@@ -697,9 +697,11 @@ extern "C" int cp_dcn_v2_forward(const cp_dcn_shape* s, const float* x, const fl
 // DCN with its conv_offset_mask inside the kernel (dcn_fwd_region.hip, template FUSE).
 static size_t fused_region_bytes(const cp_dcn_shape* s) { return cp_align_up(cp_dcn_region_wperm_bytes(s), 256); }
 
-// One 64-channel block only: with more, every block's workgroups would repeat the offset convolution of their tile.
+// One 64-channel block only (with more, every block's workgroups would repeat the offset convolution of their tile) and
+// at most 64 input channels: measured at 128 -> 64 @128x256 the in-kernel pass (8 chunks on 128 workgroups, 81 us in
+// all) does not beat the stand-alone convolution with its K split (58 + 20 us); at 64 -> 64 @256x512 it does (64 vs 89).
 extern "C" int cp_dcn_v2_forward_fused_supported(const cp_dcn_shape* s) {
-  return s && s->B > 0 && s->Cout > 0 && s->Cout <= 64 && cp_dcn_region_supported(s) && region_pays(s) ? 1 : 0;
+  return s && s->B > 0 && s->Cout > 0 && s->Cout <= 64 && s->Cin <= 64 && cp_dcn_region_supported(s) && region_pays(s) ? 1 : 0;
 }
 
 extern "C" size_t cp_dcn_v2_forward_fused_workspace_bytes(const cp_dcn_shape* s) {

@@ -4,7 +4,8 @@
 set -u
 cd "$(dirname "$0")/.."
 tag=${1:-r03}
-P=profiles
+P=gpurun_out/publish_$tag          # (only gpurun_out/ travels back from the GPU box: copy P/* into profiles/ afterwards)
+mkdir -p $P
 log=gpurun_out/evidence_$tag.log
 mkdir -p gpurun_out
 step() { echo "[$(date +%H:%M:%S)] $*" | tee -a $log; }

@@ -72,7 +72,7 @@ if len(sys.argv) > 4:
 
 # ---- and for the fused heads launch (csrc/heads_fused.hip): 512 tiles x 4 heads x 256 threads ----
 if len(sys.argv) > 5:
-    fetch, write = avg(sys.argv[1], "FETCH_SIZE", "conv_heads_fused_kernel"), avg(sys.argv[2], "WRITE_SIZE", "conv_heads_fused_kernel")
+    fetch, write = avg(sys.argv[1], "FETCH_SIZE", "conv_heads_fused"), avg(sys.argv[2], "WRITE_SIZE", "conv_heads_fused")
     layers, raw = {}, {}
     for grid, shape in {512 * 4 * 256: (1, 64, 1024, 256, 512)}.items():
         if grid in fetch and grid in write:
