@@ -51,6 +51,9 @@ constexpr int ITEMS = CELLS * 4 / 256;    // float4 cells staged per thread and 
 #ifndef CP_RABL
 #define CP_RABL 0
 #endif
+#ifndef CP_RPRIO
+#define CP_RPRIO 1      // per-chunk priority alternation between the workgroups sharing a CU (0: off, for A/B timing)
+#endif
 constexpr int RABL = CP_RABL;
 // diagnostic build (make libcp_rstamp.so, tools/probe_region_stamp.py): wave 0 of every workgroup overwrites 8 floats of
 // out[] with s_memtime deltas of its phases (the results are destroyed; never shipped)
@@ -485,7 +488,16 @@ __global__ __launch_bounds__(256, 2) void dcn_fwd_region_kernel(RegionArgs a) {
   RSTAMP(3);
 
   const unsigned kgoff = (unsigned)kg * (2u * PLANE);
+  const int prio_half = (int)((blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) >> 8);
   for (int c = 0; c < nchunk; ++c) {
+#if CP_RPRIO
+    // The two workgroups of a CU share its SIMDs; VALU issue goes to the older wave, so one of them finishes its K loop
+    // ~25 % later than the other and the launch waits for it.  Alternating the priority per chunk between the halves of
+    // the grid (workgroups b and b + 256 of the dispatch order are the ones that meet on a CU under round-robin
+    // placement; a wrong guess costs nothing) evens them out: 53.8 -> 49.8 us on the dominant launch.
+    if (((prio_half) ^ c) & 1) __builtin_amdgcn_s_setprio(1);
+    else __builtin_amdgcn_s_setprio(0);
+#endif
     const unsigned cur = (unsigned)(c & 1) * CHB, nxt = CHB - cur;
     const unsigned curk = cur + kgoff;
     const bool more = c + 1 < nchunk;
@@ -591,6 +603,9 @@ __global__ __launch_bounds__(256, 2) void dcn_fwd_region_kernel(RegionArgs a) {
     __syncthreads();                        // next chunk staged, this one no longer read
   }
 
+#if CP_RPRIO
+  __builtin_amdgcn_s_setprio(0);
+#endif
   RSTAMP(4);
   // ------------------------------------------------------------------ epilogue: D[co][pixel]
   // Accumulator layout: lane = pixel column (+ 4 channels per lane half), registers = channels.  Through LDS (the

@@ -39,7 +39,9 @@ def run(L, B, ci, co, H, W, scale, n=40):
 
 
 only = [int(v) for v in sys.argv[1:]]
-libs = [(0, _C.LIB_PATH)] + sorted((int(os.path.basename(p)[11:-3]), p) for p in glob.glob(os.path.join(LIBDIR, "libcp_rabl_*.so")))
+extra = [(200, os.path.join(LIBDIR, "libcp_rprio.so"))] if os.path.exists(os.path.join(LIBDIR, "libcp_rprio.so")) else []
+BITS[200] = "full, WITHOUT the per-chunk priority alternation between the workgroups of a CU"
+libs = [(0, _C.LIB_PATH)] + extra + sorted((int(os.path.basename(p)[11:-3]), p) for p in glob.glob(os.path.join(LIBDIR, "libcp_rabl_*.so")))
 for shape in [(1, 64, 64, 256, 512), (1, 128, 128, 128, 256)]:
     for scale in (0.3,):
         for mask, path in libs:
