@@ -721,7 +721,7 @@ def test_deformconv_training_path_backward():
                                    atol=3e-5 * want.abs().max().item(), err_msg=k)
 
 
-@pytest.mark.parametrize("f,C,H,W", [(2, 64, 16, 24), (4, 8, 9, 11), (8, 5, 6, 7), (2, 3, 5, 6)])
+@pytest.mark.parametrize("f,C,H,W", [(2, 64, 16, 24), (4, 8, 9, 11), (8, 5, 6, 7), (2, 3, 5, 6), (2, 5, 7, 10), (2, 4, 1, 2), (2, 3, 6, 130)])
 def test_depthwise_up_add_vs_conv_transpose(f, C, H, W):
     from centerpoly_amd.models.networks.pose_dla_dcn import depthwise_up_add, fill_up_weights
     up = torch.nn.ConvTranspose2d(C, C, f * 2, stride=f, padding=f // 2, groups=C, bias=False)
