@@ -299,8 +299,10 @@ __global__ __launch_bounds__(TH * 64, TH / 4) void dcn_bwd_data2_kernel(D2Args a
     float l1 = l1_lane;
     l1 += __shfl_xor(l1, 16, 64);
     l1 += __shfl_xor(l1, 32, 64);
+    // (fmaxf drops a NaN operand: nan_max keeps it, so that a non-finite grad_out reaches the scale test below)
+    auto nan_max = [](float p, float q) { return p != p ? p : (q != q ? q : fmaxf(p, q)); };
 #pragma unroll
-    for (int o = 8; o > 0; o >>= 1) l1 = fmaxf(l1, __shfl_xor(l1, o, 64));
+    for (int o = 8; o > 0; o >>= 1) l1 = nan_max(l1, __shfl_xor(l1, o, 64));
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) lane_mmax = fmaxf(lane_mmax, __shfl_xor(lane_mmax, o, 64));
     if (lane == 0) wred[wid] = l1 * lane_mmax;
@@ -312,13 +314,18 @@ __global__ __launch_bounds__(TH * 64, TH / 4) void dcn_bwd_data2_kernel(D2Args a
   if (WANT_GX) {
     float l1 = wred[0];
 #pragma unroll
-    for (int i = 1; i < TH; ++i) l1 = fmaxf(l1, wred[i]);
+    for (int i = 1; i < TH; ++i) l1 = (l1 != l1) ? l1 : (wred[i] != wred[i] ? wred[i] : fmaxf(l1, wred[i]));
     const float gb = l1 * a.wmax[0] * 1.0001f;
     if (gb > 0.f && gb < 3.0e38f) {
       int ge = 0;
       (void)frexpf(gb, &ge);
       fx_scale = ldexp(1.0, 35 - ge);
       fx_inv = ldexp(1.0, ge - 35);
+    } else if (!(gb == 0.f)) {
+      // grad_out of this tile holds Inf / NaN (a loss overflow): no fixed-point scale exists.  The sums stay 0 and
+      // the flush multiplies them by NaN, so the tile's grad_x comes out NaN, as the reference's float chain would,
+      // instead of silently zero (grad_offset / grad_mask carry the NaN through their float sums anyway).
+      fx_inv = __builtin_nan("");
     }
   }
 

@@ -662,6 +662,31 @@ def test_dcn_backward_overwrites_grad_x_and_flags(scale):
                                 _C.ptr(gog), None, None, bs, None, bs, None, None, 64, _C.ptr(ws), nws, _C.stream()) == -1
 
 
+def test_dcn_backward_propagates_non_finite_grad_out():
+    """A NaN / Inf in grad_out (a loss overflow) must reach grad_x as NaN, not as silent zeros: the fixed-point
+    accumulation of the data-gradient kernel has no scale for such a tile and flushes NaN instead."""
+    L = _C.lib()
+    B, Cin, Cout, H, W = 1, 64, 64, 24, 40
+    x, om, w, b = _dcn_inputs("nan", B, Cin, Cout, H, W, offset_scale=0.3)
+    go = synth.normal("dcn/nan/go", (B, Cout, H, W))
+    go[0, 3, 10, 17] = np.float32("nan")
+    go[0, 5, 20, 3] = np.float32("inf")
+    s = _C.DcnShape(B, Cin, H, W, Cout, 3, 3, 1, 1, 1, 1)
+    xg, omg, wg, gog = g(x), g(om), g(w), g(go)
+    bs, off_m = 27 * H * W, 4 * 18 * H * W
+    nws = L.cp_dcn_v2_backward_workspace_bytes(s)
+    ws = _C.workspace(nws, xg.device)
+    gx, gom = torch.empty_like(xg), torch.empty_like(omg)
+    rc = L.cp_dcn_v2_backward(s, _C.ptr(xg), _C.ptr(omg), bs, _C.c_void_p(omg.data_ptr() + off_m), bs, 1, _C.ptr(wg),
+                              _C.ptr(gog), _C.ptr(gx), _C.ptr(gom), bs, _C.c_void_p(gom.data_ptr() + off_m), bs,
+                              None, None, 0, _C.ptr(ws), nws, _C.stream())
+    _C.check(rc, "cp_dcn_v2_backward")
+    gx = gx.cpu()
+    assert not torch.isfinite(gx[0, :, 8:13, 14:21]).all() and not torch.isfinite(gx[0, :, 18:23, 1:6]).all()
+    assert not torch.isfinite(gom.cpu()[0, :, 10, 17]).all()
+    assert torch.isfinite(gx[0, :, 0:4, 30:40]).all()          # tiles away from the bad pixels are untouched
+
+
 def test_dcn_backward_finite_difference():
     """Independent of the oracle: central differences on a scalar loss through the HIP forward."""
     from centerpoly_amd.models.networks.DCNv2.dcn_v2 import _DCNv2Function, dcn_v2_forward_raw
