@@ -174,6 +174,83 @@ class _DCNv2Function(torch.autograd.Function):
         return gx, gom, gw, (gb if ctx.has_bias else None), None, None, None, None
 
 
+def _dcn_backward(x, om, weight, grad_out, has_bias):
+    """cp_dcn_v2_backward on the raw 27-channel tensor: (grad_x, grad_om, grad_weight, grad_bias)."""
+    L = _C.lib()
+    s = _shape(x, weight, 1, 1, 1, 1)
+    K = 9
+    Ho, Wo = om.shape[2], om.shape[3]
+    grad_out = grad_out.contiguous()
+    gx = torch.empty_like(x)                             # (overwritten: the library zero-fills it itself)
+    gom = torch.empty_like(om)
+    gw = torch.zeros_like(weight)
+    gb = torch.zeros((s.Cout,), dtype=torch.float32, device=x.device)
+    bs = 3 * K * Ho * Wo
+    off_m = 4 * 2 * K * Ho * Wo
+    ws = _C.workspace(L.cp_dcn_v2_backward_workspace_bytes(s), x.device)
+
+    def call(data, wgt, bias_):
+        rc = L.cp_dcn_v2_backward(s, _C.ptr(x), _C.ptr(om), bs, _C.c_void_p(om.data_ptr() + off_m),
+                                  bs, 1, _C.ptr(weight), _C.ptr(grad_out),
+                                  _C.ptr(gx) if data else None, _C.ptr(gom) if data else None, bs,
+                                  _C.c_void_p(gom.data_ptr() + off_m) if data else None, bs, _C.ptr(gw) if wgt else None,
+                                  _C.ptr(gb) if bias_ else None, DCN.backward_flags, _C.ptr(ws), ws.numel(),
+                                  _C.stream())
+        _C.check(rc, "cp_dcn_v2_backward")
+
+    timer = _C.kernel_timer
+    if timer is None:
+        call(True, True, True)
+    else:
+        key = (s.Cin, s.Cout, Ho, Wo, s.B)
+        for tag, sel in (("dcn_bwd_data", (True, False, False)), ("dcn_bwd_weight", (False, True, False)),
+                         ("dcn_bwd_bias", (False, False, True))):
+            end = timer.start((tag,) + key)
+            call(*sel)
+            end.record()
+    return gx, gom, gw, (gb if has_bias else None)
+
+
+class _DCNModuleFunction(torch.autograd.Function):
+    """The whole DCN module (3x3, stride 1, pad 1) as ONE autograd node: x -> conv_offset_mask -> deformable convolution.
+    Forward: cp_dcn_v2_forward_fused where the library fuses the offset convolution into the DCN kernel (it copies the
+    27 channels out for the backward), else the convolution kernel + cp_dcn_v2_forward.  Backward: cp_dcn_v2_backward,
+    then the convolution's gradients with the DCN's grad_x riding in the input-gradient kernel's epilogue -- one grad_x
+    leaves the node, autograd has no `add` to run (16 full-map adds per step before)."""
+
+    @staticmethod
+    def forward(ctx, x, om_weight, om_bias, weight, bias):
+        from .. import conv3x3
+        x = x.contiguous()
+        r = dcn_v2_module_forward(x, om_weight, om_bias, weight, bias, want_om=True) \
+            if DCN.fuse_offset_conv and DCN.train_contraction in ("auto", "bf16x3") else None
+        if r is not None:
+            out, om = r
+        else:
+            cout, cin = om_weight.shape[0], om_weight.shape[1]
+            om = conv3x3._launch(x, conv3x3._prepare(om_weight, cin, cout, False), om_bias, None, cout, False, 9)
+            out = dcn_v2_forward_raw(x, om, weight, bias, 1, 1, 1, 1, contraction=DCN.train_contraction)
+        ctx.save_for_backward(x, om, weight, om_weight)
+        ctx.has_bias = bias is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        from .. import conv3x3
+        x, om, weight, om_weight = ctx.saved_tensors
+        gx, gom, gw, gb = _dcn_backward(x, om, weight, grad_out, ctx.has_bias)
+        B, C, H, W = gom.shape
+        L = _C.lib()
+        gb_om = torch.zeros(C, dtype=torch.float32, device=gom.device)
+        _C.check(L.cp_channel_sum_accumulate(_C.ptr(gom), _C.ptr(gb_om), B, C, H * W, _C.stream()), "cp_channel_sum_accumulate")
+        _, gw_om = conv3x3.grads(x, om_weight, gom, want_x=False, want_w=True)
+        cin = om_weight.shape[1]
+        # input gradient of the offset convolution (the forward kernel over grad_om with the transposed, flipped weights)
+        # + the DCN's own grad_x as the kernel's residual operand
+        gx_all = conv3x3._launch(gom, conv3x3._prepare(om_weight, C, cin, True), None, gx, cin, False, 9)
+        return gx_all, gw_om, gb_om, gw, gb
+
+
 class _ConvBias(torch.autograd.Function):
     """y_raw + bias[c] in place on a convolution's raw output; the bias gradient is one
     segmented channel sum (cp_channel_sum_accumulate) instead of torch's generic reduction."""
@@ -252,7 +329,13 @@ class DCN(nn.Module):
             self.conv_offset_mask.bias.zero_()
 
     def forward(self, x):
-        om = conv_bias(self.conv_offset_mask, x)
+        cm = self.conv_offset_mask
+        if x.is_cuda and x.dtype == torch.float32 and torch.is_grad_enabled() and self.stride == 1 and self.padding == 1 \
+                and self.dilation == 1 and self.deformable_groups == 1 and self.kernel_size == (3, 3) and cm.bias is not None:
+            from .. import conv3x3
+            if conv3x3.usable(cm, x) and _C.lib().cp_conv3x3_mfma_supported(27, x.shape[1], x.shape[2], x.shape[3]):
+                return _DCNModuleFunction.apply(x, cm.weight, cm.bias, self.weight, self.bias)
+        om = conv_bias(cm, x)
         return _DCNv2Function.apply(x, om, self.weight, self.bias, self.stride, self.padding,
                                     self.dilation, self.deformable_groups)
 

@@ -621,6 +621,55 @@ def test_dcn_backward_vs_oracle_autograd(shape):
                                    err_msg="grad_" + name)
 
 
+@pytest.mark.parametrize("shape", [(2, 64, 64, 64, 128), (1, 128, 64, 128, 128)], ids=["64->64 fused forward", "128->64 separate conv"])
+def test_dcn_module_single_autograd_node(shape):
+    """DCN.forward in training on maps the MFMA convolution takes: one autograd node for conv_offset_mask + the deformable
+    convolution (forward through cp_dcn_v2_forward_fused where the library fuses them), gradients of x, both weights
+    and both biases against torch autograd through conv2d + the oracle's DCN."""
+    from centerpoly_amd.models.networks.DCNv2.dcn_v2 import DCN, _DCNModuleFunction
+    B, Cin, Cout, H, W = shape
+    d = DCN(Cin, Cout, kernel_size=(3, 3), stride=1, padding=1, dilation=1, deformable_groups=1).to(DEV)
+    with torch.no_grad():
+        d.weight.copy_(g(synth.normal("dcn/node/w%d" % Cin, (Cout, Cin, 3, 3), 0.0, 1.0 / np.sqrt(Cin * 9))))
+        d.bias.copy_(g(synth.normal("dcn/node/b", (Cout,), 0.0, 0.1)))
+        d.conv_offset_mask.weight.copy_(g(synth.normal("dcn/node/wom%d" % Cin, (27, Cin, 3, 3), 0.0, 0.03)))
+        d.conv_offset_mask.bias.copy_(g(synth.normal("dcn/node/bom", (27,), 0.0, 0.3)))
+    x = g(synth.normal("dcn/node/x%d" % Cin, (B, Cin, H, W))).requires_grad_(True)
+    go = g(synth.normal("dcn/node/go%d" % Cin, (B, Cout, H, W)))
+    out = d(x)
+    assert type(out.grad_fn).__name__ == "_DCNModuleFunctionBackward"
+    params = [d.weight, d.bias, d.conv_offset_mask.weight, d.conv_offset_mask.bias]
+    grads = torch.autograd.grad(out, [x] + params, go)
+    # Reference: the oracle's DCN differentiated at the offsets / mask logits the KERNEL computed (the same 27 channels the
+    # node saved for its backward -- two float convolutions would differ in the last bits, and a sample within ~1e-5 px
+    # of an integer position would land on the other side of a bilinear kink, where grad_offset jumps), then the
+    # convolution's gradients from that grad_om with torch.
+    from centerpoly_amd.models.networks import conv3x3
+    from centerpoly_amd.models.networks.DCNv2.dcn_v2 import dcn_v2_module_forward
+    with torch.no_grad():
+        r = dcn_v2_module_forward(x.detach(), params[2], params[3], params[0], params[1], want_om=True)
+        om_k = r[1] if r is not None else conv3x3._launch(x.detach(), conv3x3._prepare(params[2], Cin, 27, False), params[3],
+                                                          None, 27, False, 9)
+    om_ref = torch.nn.functional.conv2d(x.detach().cpu().double(), params[2].detach().cpu().double(),
+                                        params[3].detach().cpu().double(), padding=1)
+    assert (om_k.cpu().double() - om_ref).abs().max().item() <= 3e-5 * om_ref.abs().max().item()
+    tx = x.detach().cpu().requires_grad_(True)
+    tom = om_k.cpu().requires_grad_(True)
+    tw, tb = params[0].detach().cpu().requires_grad_(True), params[1].detach().cpu().requires_grad_(True)
+    o1, o2, m = torch.chunk(tom, 3, dim=1)
+    ref = odcn.dcn_v2_forward(tx, torch.cat((o1, o2), 1), torch.sigmoid(m), tw, tb)
+    s_ = ref.abs().max().item()
+    assert (out.detach().cpu() - ref.detach()).abs().max().item() <= 1e-4 * s_
+    gx_d, gom, gw, gb = torch.autograd.grad(ref, [tx, tom, tw, tb], go.cpu())
+    wom = params[2].detach().cpu()
+    gx_c = torch.nn.grad.conv2d_input(tuple(tx.shape), wom, gom, padding=1)
+    gw_c = torch.nn.grad.conv2d_weight(tx.detach(), tuple(wom.shape), gom, padding=1)
+    want = [gx_d + gx_c, gw, gb, gw_c, gom.sum(dim=(0, 2, 3))]
+    for name, a, b in zip(("x", "weight", "bias", "conv_offset_mask.weight", "conv_offset_mask.bias"), grads, want):
+        scale = b.abs().max().item()
+        np.testing.assert_allclose(a.cpu().numpy(), b.numpy(), rtol=2e-3, atol=3e-4 * scale, err_msg="grad_" + name)
+
+
 @pytest.mark.parametrize("scale", [0.3, 6.0], ids=["window", "cold"])
 def test_dcn_backward_overwrites_grad_x_and_flags(scale):
     """cp_dcn_v2_backward's contract: grad_x is OVERWRITTEN whatever it holds -- also when taps leave the staged
