@@ -36,7 +36,12 @@ constexpr unsigned OOB = 0xFFFFFFF0u;
 //   half(hl) of Wsrc[m = ct * 16 + (lane & 15)][k = chunk * 32 + 8 (lane >> 4) + j][tap]        (ct: 16-row tile)
 // taps = 9 (3x3) or 1 (1x1).  Wsrc = W ([M][K][taps]) or, transposed (input gradient):
 // Wsrc[m][k][tap] = W[k][m][taps - 1 - tap] with W = [K][M][taps].
+// transposed = 2 + 2 py + px (stride-2 input gradient, parity class (py, px) of the output rows / columns; W = [K][M][3][3]):
+// the class's gradient is a stride-1 convolution of grad_out whose tap (ty, tx) (rows i - 1 + ty of grad_out) carries
+// W[k][m][ky][kx] with ky = class_tap(py, ty): py = 0: ty 1 -> ky 1;  py = 1: ty 1 -> ky 2, ty 2 -> ky 0; other taps 0.
 // Rows past M (the tile count is rounded up to a multiple of 4) and k past K are zero.
+__device__ __forceinline__ int s2_class_tap(int par, int t) { return par == 0 ? (t == 1 ? 1 : -1) : (t == 1 ? 2 : (t == 2 ? 0 : -1)); }
+
 __global__ __launch_bounds__(256) void conv_mfma_wperm_kernel(const float* __restrict__ w, bf16x8* __restrict__ wp, int M,
                                                               int K, int nchunk, int taps, int transposed, int total) {
   const int e = blockIdx.x * 256 + threadIdx.x;
@@ -54,8 +59,14 @@ __global__ __launch_bounds__(256) void conv_mfma_wperm_kernel(const float* __res
   for (int j = 0; j < 8; ++j) {
     const int k = chunk * KC + 8 * (lane >> 4) + j;
     float v = 0.f;
-    if (m < M && k < K)
-      v = transposed ? w[((long long)k * M + m) * taps + (taps - 1 - tap)] : w[((long long)m * K + k) * taps + tap];
+    if (m < M && k < K) {
+      if (transposed >= 2) {
+        const int ky = s2_class_tap((transposed - 2) >> 1, tap / 3), kx = s2_class_tap((transposed - 2) & 1, tap % 3);
+        if (ky >= 0 && kx >= 0) v = w[((long long)k * M + m) * 9 + ky * 3 + kx];
+      } else {
+        v = transposed ? w[((long long)k * M + m) * taps + (taps - 1 - tap)] : w[((long long)m * K + k) * taps + tap];
+      }
+    }
     const __bf16 h = (__bf16)v;
     o[j] = hl ? (__bf16)(v - (float)h) : h;
   }
@@ -70,7 +81,11 @@ struct CvArgs {
   const float* bias;      // [Cout] or null
   const float* res;       // same shape as out, or null
   float* out;
-  int Cin, H, W, Ho, Wo, Cout, nchunk, ncot, tiles_x, relu;   // H, W: input; Ho, Wo: output
+  int Cin, H, W, Ho, Wo, Cout, nchunk, ncot, tiles_x, relu;   // H, W: input; Ho, Wo: output grid of the launch
+  // output placement: element (y, x) of the launch's grid goes to row os * y + oy, column os * x + ox of a map of
+  // Hf x Wf (plain convolutions: os 1, oy = ox 0, Hf x Wf = Ho x Wo; stride-2 input gradient: one parity class per launch)
+  int os, oy, ox, Hf, Wf;
+  unsigned tapmask;            // taps whose weights are not identically zero (bit = tap index; all ones normally)
 };
 
 // KS > 1 (deep, small layers whose grid cannot fill the chip -- one wave per SIMD exposes every load latency): the
@@ -98,7 +113,7 @@ __global__ __launch_bounds__(256 * KS, KS > 1 ? 4 : 2) void conv_mfma_kernel(CvA
   const int tid = threadIdx.x & 255, lane = tid & 63, wid = tid >> 6, g = lane >> 4, c = lane & 15;
   const int cot = blockIdx.x % a.ncot, tile = blockIdx.x / a.ncot;
   const int x0 = (tile % a.tiles_x) * TW, y0 = (tile / a.tiles_x) * TH, b = blockIdx.y;
-  const int HW = a.H * a.W, HWo = a.Ho * a.Wo;              // input / output plane sizes
+  const int HW = a.H * a.W;                                  // input plane size
 
   // staging units of this thread: (channel group, row, col) -> byte offset of channel 0 of the group, or OOB
   unsigned soff[ITERS];
@@ -180,6 +195,7 @@ __global__ __launch_bounds__(256 * KS, KS > 1 ? 4 : 2) void conv_mfma_kernel(CvA
 #pragma unroll
     for (int tap = 0; tap < TAPS; ++tap) {
       const int dy = tap / 3, dx = tap % 3;
+      const bool tap_on = (a.tapmask >> tap) & 1u;             // (wave-uniform; stride-2 input gradient: 1, 2 or 4 of 9)
       // next tap's (or this group's next chunk's first) weight fragments; past the end: re-read the last
       bf16x8 an[MT][2];
       {
@@ -192,21 +208,23 @@ __global__ __launch_bounds__(256 * KS, KS > 1 ? 4 : 2) void conv_mfma_kernel(CvA
           an[m][1] = nq[m * tstride + 64];
         }
       }
-      bf16x8 bh[NT], bl[NT];
-#pragma unroll
-      for (int n = 0; n < NT; ++n) {
-        const int idx = bbase + (S * (n >> 1) + dy) * LW + S * (n & 1) * 16 + dx;
-        bh[n] = Xs[idx];
-        bl[n] = Xs[PLANE + idx];
-      }
-#pragma unroll
-      for (int m = 0; m < MT; ++m)
+      if (tap_on) {
+        bf16x8 bh[NT], bl[NT];
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
-          acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[m][0], bh[n], acc[m][n], 0, 0, 0);
-          acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[m][0], bl[n], acc[m][n], 0, 0, 0);
-          acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[m][1], bh[n], acc[m][n], 0, 0, 0);
+          const int idx = bbase + (S * (n >> 1) + dy) * LW + S * (n & 1) * 16 + dx;
+          bh[n] = Xs[idx];
+          bl[n] = Xs[PLANE + idx];
         }
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int n = 0; n < NT; ++n) {
+            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[m][0], bh[n], acc[m][n], 0, 0, 0);
+            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[m][0], bl[n], acc[m][n], 0, 0, 0);
+            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[m][1], bh[n], acc[m][n], 0, 0, 0);
+          }
+      }
 #pragma unroll
       for (int m = 0; m < MT; ++m) {
         af[m][0] = an[m][0];
@@ -236,8 +254,9 @@ __global__ __launch_bounds__(256 * KS, KS > 1 ? 4 : 2) void conv_mfma_kernel(CvA
   }
 
   // epilogue: D[row = 4 g + r (co)][col = c (pixel)]
-  float* ob = a.out + (long long)b * a.Cout * HWo;
-  const float* rb = a.res ? a.res + (long long)b * a.Cout * HWo : nullptr;
+  const int HWf = a.Hf * a.Wf;
+  float* ob = a.out + (long long)b * a.Cout * HWf;
+  const float* rb = a.res ? a.res + (long long)b * a.Cout * HWf : nullptr;
 #pragma unroll
   for (int m = 0; m < MT; ++m) {
 #pragma unroll
@@ -249,7 +268,7 @@ __global__ __launch_bounds__(256 * KS, KS > 1 ? 4 : 2) void conv_mfma_kernel(CvA
       for (int n = 0; n < NT; ++n) {
         const int y = y0 + wid * RW + (n >> 1), x = x0 + (n & 1) * 16 + c;
         if (y < a.Ho && x < a.Wo) {
-          const long long o = (long long)co * HWo + (long long)y * a.Wo + x;
+          const long long o = (long long)co * HWf + (long long)(a.os * y + a.oy) * a.Wf + (a.os * x + a.ox);
           float v = acc[m][n][r] + bv;
           if (rb) v += rb[o];
           if (a.relu) v = fmaxf(v, 0.f);
@@ -300,37 +319,8 @@ int cp_conv3x3_mfma_prepare(const float* weight, int32_t Cin, int32_t Cout, int3
 // The input is the channel concatenation of `nsrc` (1..4) tensors xs[i] = [B][cs[i]][H][W] (what the reference
 // builds with torch.cat before a 1x1 `Root` convolution, pose_dla_dcn.py:148-166) -- read in place, never
 // materialised.  With several sources every cs[i] must be a multiple of 32.  taps = 9: 3x3 / pad 1; taps = 1: 1x1.
-int cp_conv_mfma_forward_strided(const float* const* xs, const int32_t* cs, int32_t nsrc, const void* wperm,
-                                 const float* bias, const float* residual, float* out, int32_t B, int32_t H, int32_t W,
-                                 int32_t Cout, int32_t taps, int32_t stride, int32_t relu, void* stream) {
-  hipStream_t st = (hipStream_t)stream;
-  CP_CHECK_ARG(xs && cs && wperm && out && B >= 1 && nsrc >= 1 && nsrc <= MAXSRC && (taps == 1 || taps == 9));
-  if (stride != 1 && stride != 2) return CP_EUNSUPPORTED;
-  CvArgs a;
-  int Cin = 0;
-  for (int i = 0; i < MAXSRC; ++i) {
-    a.xsrc[i] = i < nsrc ? xs[i] : nullptr;
-    a.csrc[i] = i < nsrc ? cs[i] : 0;
-    if (i < nsrc) {
-      CP_CHECK_ARG(xs[i] && cs[i] >= 1);
-      if (nsrc > 1 && cs[i] % KC != 0) return CP_EUNSUPPORTED;
-      if (!cp_conv3x3_mfma_supported(cs[i], Cout, H, W)) return CP_EUNSUPPORTED;
-      Cin += cs[i];
-    }
-  }
-  a.wp = (const bf16x8*)wperm;
-  a.bias = bias;
-  a.res = residual;
-  a.out = out;
-  a.Cin = Cin;
-  a.H = H;
-  a.W = W;
-  a.Cout = Cout;
-  a.Ho = (H - 1) / stride + 1;                       // (pad = k / 2)
-  a.Wo = (W - 1) / stride + 1;
-  a.nchunk = (Cin + KC - 1) / KC;
-  a.tiles_x = (a.Wo + TW - 1) / TW;
-  a.relu = relu;
+// Tile-variant choice and launch for a filled-in argument block (a.Ho x a.Wo: the launch's output grid).
+static int conv_dispatch(CvArgs& a, int B, int Cout, int taps, int stride, hipStream_t st) {
   const int Ho = a.Ho;
   // Tile variant by how many workgroups it yields (the chip wants >= 2 per CU): 64 output channels x 8 rows is the
   // most efficient (fewest fragment bytes per MFMA); layers that cannot fill the CUs with it take 32 channels
@@ -364,6 +354,78 @@ int cp_conv_mfma_forward_strided(const float* const* xs, const int32_t* cs, int3
     else launch(conv_mfma_kernel<2, 1, 1>, 2, 4, 1);
   }
   return cp_launch_status();
+}
+
+int cp_conv_mfma_forward_strided(const float* const* xs, const int32_t* cs, int32_t nsrc, const void* wperm,
+                                 const float* bias, const float* residual, float* out, int32_t B, int32_t H, int32_t W,
+                                 int32_t Cout, int32_t taps, int32_t stride, int32_t relu, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  CP_CHECK_ARG(xs && cs && wperm && out && B >= 1 && nsrc >= 1 && nsrc <= MAXSRC && (taps == 1 || taps == 9));
+  if (stride != 1 && stride != 2) return CP_EUNSUPPORTED;
+  CvArgs a;
+  int Cin = 0;
+  for (int i = 0; i < MAXSRC; ++i) {
+    a.xsrc[i] = i < nsrc ? xs[i] : nullptr;
+    a.csrc[i] = i < nsrc ? cs[i] : 0;
+    if (i < nsrc) {
+      CP_CHECK_ARG(xs[i] && cs[i] >= 1);
+      if (nsrc > 1 && cs[i] % KC != 0) return CP_EUNSUPPORTED;
+      if (!cp_conv3x3_mfma_supported(cs[i], Cout, H, W)) return CP_EUNSUPPORTED;
+      Cin += cs[i];
+    }
+  }
+  a.wp = (const bf16x8*)wperm;
+  a.bias = bias;
+  a.res = residual;
+  a.out = out;
+  a.Cin = Cin;
+  a.H = H;
+  a.W = W;
+  a.Cout = Cout;
+  a.Ho = (H - 1) / stride + 1;                       // (pad = k / 2)
+  a.Wo = (W - 1) / stride + 1;
+  a.nchunk = (Cin + KC - 1) / KC;
+  a.tiles_x = (a.Wo + TW - 1) / TW;
+  a.relu = relu;
+  a.os = 1; a.oy = 0; a.ox = 0; a.Hf = a.Ho; a.Wf = a.Wo;
+  a.tapmask = 0x1ffu;
+  return conv_dispatch(a, B, Cout, taps, stride, st);
+}
+
+// INPUT GRADIENT of a 3x3 / stride 2 / pad 1 convolution (the first convolution of DLA levels 2-5, pose_dla_dcn.py:38-46;
+// what the reference gets from cuDNN's backward-data), one parity class of the input rows / columns per call:
+//   grad_in[b][ci][2 i + py][2 j + px] = sum_{co} sum_{(ky, kx) in class} w[co][ci][ky][kx] * grad_out[b][co][i + dy(ky)][j + dx(kx)]
+// -- a stride-1 convolution of grad_out with 1, 2, 2 or 4 of the nine taps (no multiplications by inserted zeros; the four
+// classes together do exactly the forward's work) whose results are written to every second row / column of grad_in.
+// wperm_class: cp_conv_mfma_prepare(w, Cin := Cout of the convolution, Cout := its Cin, taps 9, transposed = 2 + 2 py + px).
+// grad_out [B][Cout][Ho][Wo] with Ho = (H - 1) / 2 + 1; grad_in [B][Cin][H][W]: the four calls write every element.
+int cp_conv3x3_s2_input_grad_class(const float* grad_out, const void* wperm_class, float* grad_in, int32_t B, int32_t Cin,
+                                   int32_t H, int32_t W, int32_t Cout, int32_t py, int32_t px, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  CP_CHECK_ARG(grad_out && wperm_class && grad_in && B >= 1 && Cin >= 1 && Cout >= 1 && H >= 1 && W >= 1);
+  CP_CHECK_ARG((py == 0 || py == 1) && (px == 0 || px == 1));
+  const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+  if (!cp_conv3x3_mfma_supported(Cout, Cin, Ho, Wo) || (long long)Cin * H * W * 4 >= 0x7FFFFFF0ll) return CP_EUNSUPPORTED;
+  const int ny = (H - py + 1) / 2, nx = (W - px + 1) / 2;            // rows / columns of this class
+  if (ny <= 0 || nx <= 0) return CP_OK;
+  CvArgs a;
+  for (int i = 0; i < MAXSRC; ++i) {
+    a.xsrc[i] = i == 0 ? grad_out : nullptr;
+    a.csrc[i] = i == 0 ? Cout : 0;
+  }
+  a.wp = (const bf16x8*)wperm_class;
+  a.bias = nullptr; a.res = nullptr; a.out = grad_in;
+  a.Cin = Cout; a.H = Ho; a.W = Wo; a.Cout = Cin;
+  a.Ho = ny; a.Wo = nx;
+  a.nchunk = (Cout + KC - 1) / KC;
+  a.tiles_x = (nx + TW - 1) / TW;
+  a.relu = 0;
+  a.os = 2; a.oy = py; a.ox = px; a.Hf = H; a.Wf = W;
+  const unsigned rows = py ? 0x6u : 0x2u, cols = px ? 0x6u : 0x2u;   // tap rows / columns in use (bit = index 0..2)
+  a.tapmask = 0;
+  for (int t = 0; t < 9; ++t)
+    if (((rows >> (t / 3)) & 1u) && ((cols >> (t % 3)) & 1u)) a.tapmask |= 1u << t;
+  return conv_dispatch(a, B, Cin, 9, 1, st);
 }
 
 int cp_conv_mfma_forward(const float* const* xs, const int32_t* cs, int32_t nsrc, const void* wperm, const float* bias,

@@ -134,6 +134,31 @@ def conv3x3_infer(x, owner, w, bias=None, residual=None, relu=False, conv=None, 
     return conv_infer([x], owner, w, bias, residual, relu, conv=conv, key=key)
 
 
+def s2_input_grad(xshape, weight, go):
+    """Input gradient of a 3x3 / stride 2 / pad 1 convolution: four parity-class launches of the MFMA convolution over
+    grad_out (cp_conv3x3_s2_input_grad_class); None where the kernel does not take the shape."""
+    L = _C.lib()
+    B, cin, H, W = xshape
+    cout = weight.shape[0]
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    if not (_ENABLED and go.is_cuda and go.dtype == torch.float32 and tuple(weight.shape[2:]) == (3, 3)
+            and tuple(go.shape) == (B, cout, Ho, Wo) and cout >= MIN_CIN and L.cp_conv3x3_mfma_supported(cout, cin, Ho, Wo)
+            and cin * H * W * 4 < 0x7FFFFFF0 and _fills(B, cout, cin, Ho, Wo)):
+        return None
+    go = go.contiguous()
+    gx = torch.empty(xshape, dtype=torch.float32, device=go.device)
+    nbytes = L.cp_conv_mfma_weight_bytes(cout, cin, 9)
+    end = _C.kernel_timer.start(("conv3x3s2_igrad", cout, cin, Ho, Wo, B)) if _C.kernel_timer is not None else None
+    for cls in range(4):
+        wp = torch.empty(nbytes, dtype=torch.uint8, device=go.device)
+        _C.check(L.cp_conv_mfma_prepare(_C.ptr(weight), cout, cin, 9, 2 + cls, _C.ptr(wp), _C.stream()), "cp_conv_mfma_prepare")
+        _C.check(L.cp_conv3x3_s2_input_grad_class(_C.ptr(go), _C.ptr(wp), _C.ptr(gx), B, cin, H, W, cout, cls >> 1, cls & 1,
+                                                  _C.stream()), "cp_conv3x3_s2_input_grad_class")
+    if end is not None:
+        end.record()
+    return gx
+
+
 class _Conv3x3Fn(torch.autograd.Function):
     """Training: forward and input gradient on the matrix cores (the input gradient is the same kernel
     over grad_out with the transposed, flipped weights); weight gradient by cp_conv3x3_mfma_wgrad."""
@@ -150,9 +175,12 @@ class _Conv3x3Fn(torch.autograd.Function):
     def backward(ctx, go):
         x, weight = ctx.saved_tensors
         go = go.contiguous()
-        if ctx.stride != 1:                           # stride 2: the kernel has the forward only
-            gx = torch.nn.grad.conv2d_input(x.shape, weight, go, stride=ctx.stride, padding=1) \
-                if ctx.needs_input_grad[0] else None
+        if ctx.stride != 1:                           # stride 2: forward and input gradient from the kernel
+            gx = None
+            if ctx.needs_input_grad[0]:
+                gx = s2_input_grad(x.shape, weight, go)
+                if gx is None:
+                    gx = torch.nn.grad.conv2d_input(x.shape, weight, go, stride=ctx.stride, padding=1)
             gw = torch.nn.grad.conv2d_weight(x, weight.shape, go, stride=ctx.stride, padding=1) \
                 if ctx.needs_input_grad[1] else None
             return gx, gw, None

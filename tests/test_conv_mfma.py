@@ -331,8 +331,28 @@ def test_stride_2_pointwise_forward(shape):
     assert torch.isfinite(out).all() and _rel(out, ref) <= TOL
 
 
+@pytest.mark.parametrize("shape", [(2, 32, 64, 40, 72), (1, 64, 128, 17, 33), (1, 128, 256, 64, 128), (2, 256, 512, 32, 64),
+                                   (1, 27, 64, 12, 130), (4, 32, 64, 128, 256)],
+                         ids=["32->64", "odd map", "128->256", "256->512", "ragged channels", "level2 size / 4"])
+def test_stride_2_input_gradient(shape):
+    """cp_conv3x3_s2_input_grad_class: the four parity classes of the input gradient of a 3x3 / stride 2 / pad 1
+    convolution against torch.nn.grad.conv2d_input in float64; every element of grad_in written (NaN prefill)."""
+    B, ci, co, H, W = shape
+    L = _C.lib()
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    w, go = _t("s2gw%s" % (shape,), (co, ci, 3, 3), 0.05), _t("s2go%s" % (shape,), (B, co, Ho, Wo))
+    gx = torch.full((B, ci, H, W), float("nan"), device=DEV)
+    for cls in range(4):
+        wp = torch.empty(L.cp_conv_mfma_weight_bytes(co, ci, 9), dtype=torch.uint8, device=DEV)
+        _C.check(L.cp_conv_mfma_prepare(P(w), co, ci, 9, 2 + cls, P(wp), _C.stream()), "prepare")
+        _C.check(L.cp_conv3x3_s2_input_grad_class(P(go), P(wp), P(gx), B, ci, H, W, co, cls >> 1, cls & 1, _C.stream()), "igrad")
+    ref = torch.nn.grad.conv2d_input((B, ci, H, W), w.double(), go.double(), stride=2, padding=1)
+    assert torch.isfinite(gx).all() and _rel(gx, ref) <= TOL
+
+
 def test_stride_2_autograd_wrapper():
-    """conv_raw on a stride-2 3x3 convolution: forward from the MFMA kernel, both gradients from the library."""
+    """conv_raw on a stride-2 3x3 convolution: forward and input gradient from the MFMA kernel, weight gradient from
+    the library."""
     from centerpoly_amd.models.networks import conv3x3
     conv = torch.nn.Conv2d(64, 128, 3, stride=2, padding=1, bias=False).to(DEV)
     x = _t("s2ax", (4, 64, 64, 128)).requires_grad_(True)
