@@ -39,6 +39,7 @@ constexpr unsigned OOB = 0xFFFFFFF0u;
 // transposed = 2 + 2 py + px (stride-2 input gradient, parity class (py, px) of the output rows / columns; W = [K][M][3][3]):
 // the class's gradient is a stride-1 convolution of grad_out whose tap (ty, tx) (rows i - 1 + ty of grad_out) carries
 // W[k][m][ky][kx] with ky = class_tap(py, ty): py = 0: ty 1 -> ky 1;  py = 1: ty 1 -> ky 2, ty 2 -> ky 0; other taps 0.
+// transposed = 6 (the one-pass stride-2 input gradient, IG2): Wsrc[m][k][tap] = W[k][m][tap].
 // Rows past M (the tile count is rounded up to a multiple of 4) and k past K are zero.
 __device__ __forceinline__ int s2_class_tap(int par, int t) { return par == 0 ? (t == 1 ? 1 : -1) : (t == 1 ? 2 : (t == 2 ? 0 : -1)); }
 
@@ -60,7 +61,9 @@ __global__ __launch_bounds__(256) void conv_mfma_wperm_kernel(const float* __res
     const int k = chunk * KC + 8 * (lane >> 4) + j;
     float v = 0.f;
     if (m < M && k < K) {
-      if (transposed >= 2) {
+      if (transposed == 6) {                                   // IG2: transposed, taps in place
+        v = w[((long long)k * M + m) * 9 + tap];
+      } else if (transposed >= 2) {
         const int ky = s2_class_tap((transposed - 2) >> 1, tap / 3), kx = s2_class_tap((transposed - 2) & 1, tap % 3);
         if (ky >= 0 && kx >= 0) v = w[((long long)k * M + m) * 9 + ky * 3 + kx];
       } else {
@@ -97,8 +100,14 @@ struct CvArgs {
 // ST = 2 with TAPS = 1 (the stride-2 1x1 skip convolutions of the Hourglass residuals, large_hourglass.py:55-81): a
 // 1x1 convolution of every second pixel -- the tile geometry is the stride-1 one, the staging reads at twice the
 // coordinates, nothing that is not multiplied is staged.
-template <int MT, int RW, int TAPS, int KS = 1, int ST = 1>
+// IG2 (TAPS = 9, stride-1 geometry over grad_out): the whole input gradient of a stride-2 3x3 convolution in ONE pass --
+// the four parity classes of the gradient's rows / columns keep their own accumulators (4 x MT x NT tiles), every one
+// of the nine weight taps (ky, kx) feeds the class ((ky != 1), (kx != 1)) from the staged row / column offset
+// (ky == 0 ? 2 : 1, kx == 0 ? 2 : 1): grad_out is staged once and the matrix cores do exactly the convolution's flops.
+template <int MT, int RW, int TAPS, int KS = 1, int ST = 1, bool IG2 = false>
 __global__ __launch_bounds__(256 * KS, KS > 1 ? 4 : 2) void conv_mfma_kernel(CvArgs a) {
+  static_assert(!IG2 || (TAPS == 9 && KS == 1 && ST == 1), "IG2: 3x3, stride-1 staging, no split-K");
+  constexpr int NCLS = IG2 ? 4 : 1;
   constexpr int S = TAPS == 1 ? 1 : ST;          // stride of the staged tile's geometry
   constexpr int SUB = TAPS == 1 ? ST : 1;        // 1x1: input subsampling folded into the staging addresses
   constexpr int HALO = TAPS == 9 ? 1 : 0, LW = S * TW + (TAPS == 9 ? 3 : 1) - S;
@@ -127,11 +136,14 @@ __global__ __launch_bounds__(256 * KS, KS > 1 ? 4 : 2) void conv_mfma_kernel(CvA
   }
   const unsigned cstep = (unsigned)HW * 4u;
 
-  f32x4 acc[MT][NT];
+  f32x4 accs[NCLS][MT][NT];
 #pragma unroll
-  for (int m = 0; m < MT; ++m)
+  for (int q = 0; q < NCLS; ++q)
 #pragma unroll
-    for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int n = 0; n < NT; ++n) accs[q][m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 (&acc)[MT][NT] = accs[0];
 
   const long long tstride = (long long)a.nchunk * TAPS * 2 * 64;       // fragments per 16-row weight tile
   const bf16x8* wq = a.wp + (long long)cot * MT * tstride + lane;
@@ -194,7 +206,8 @@ __global__ __launch_bounds__(256 * KS, KS > 1 ? 4 : 2) void conv_mfma_kernel(CvA
 
 #pragma unroll
     for (int tap = 0; tap < TAPS; ++tap) {
-      const int dy = tap / 3, dx = tap % 3;
+      const int dy = IG2 ? (tap / 3 == 0 ? 2 : 1) : tap / 3, dx = IG2 ? (tap % 3 == 0 ? 2 : 1) : tap % 3;
+      const int cls = IG2 ? (tap / 3 != 1) * 2 + (tap % 3 != 1) : 0;
       const bool tap_on = (a.tapmask >> tap) & 1u;             // (wave-uniform; stride-2 input gradient: 1, 2 or 4 of 9)
       // next tap's (or this group's next chunk's first) weight fragments; past the end: re-read the last
       bf16x8 an[MT][2];
@@ -220,9 +233,10 @@ __global__ __launch_bounds__(256 * KS, KS > 1 ? 4 : 2) void conv_mfma_kernel(CvA
         for (int m = 0; m < MT; ++m)
 #pragma unroll
           for (int n = 0; n < NT; ++n) {
-            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[m][0], bh[n], acc[m][n], 0, 0, 0);
-            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[m][0], bl[n], acc[m][n], 0, 0, 0);
-            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[m][1], bh[n], acc[m][n], 0, 0, 0);
+            f32x4& d = accs[cls][m][n];
+            d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[m][0], bh[n], d, 0, 0, 0);
+            d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[m][0], bl[n], d, 0, 0, 0);
+            d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[m][1], bh[n], d, 0, 0, 0);
           }
       }
 #pragma unroll
@@ -257,6 +271,41 @@ __global__ __launch_bounds__(256 * KS, KS > 1 ? 4 : 2) void conv_mfma_kernel(CvA
   const int HWf = a.Hf * a.Wf;
   float* ob = a.out + (long long)b * a.Cout * HWf;
   const float* rb = a.res ? a.res + (long long)b * a.Cout * HWf : nullptr;
+  if (IG2) {                                                   // class (py, px) of (y, x) -> (2 y + py, 2 x + px)
+    const bool pair = (a.Wf & 1) == 0;                         // even width: the two column classes leave as one float2
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int co = (cot * MT + m) * 16 + 4 * g + r;
+        if (co >= a.Cout) continue;
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+          const int y = y0 + wid * RW + (n >> 1), x = x0 + (n & 1) * 16 + c;
+          if (y >= a.Ho || x >= a.Wo) continue;
+#pragma unroll
+          for (int py = 0; py < 2; ++py) {
+            const int Y = 2 * y + py, X = 2 * x;
+            if (Y >= a.Hf || X >= a.Wf) continue;
+            const long long o = (long long)co * HWf + (long long)Y * a.Wf + X;
+            float v0 = accs[NCLS > 1 ? 2 * py : 0][m][n][r], v1 = accs[NCLS > 1 ? 2 * py + 1 : 0][m][n][r];
+            if (pair) {
+              if (rb) {
+                const float2 q = *reinterpret_cast<const float2*>(rb + o);
+                v0 += q.x;
+                v1 += q.y;
+              }
+              *reinterpret_cast<float2*>(ob + o) = make_float2(v0, v1);
+            } else {
+              ob[o] = rb ? v0 + rb[o] : v0;
+              if (X + 1 < a.Wf) ob[o + 1] = rb ? v1 + rb[o + 1] : v1;
+            }
+          }
+        }
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int m = 0; m < MT; ++m) {
 #pragma unroll
@@ -426,6 +475,41 @@ int cp_conv3x3_s2_input_grad_class(const float* grad_out, const void* wperm_clas
   for (int t = 0; t < 9; ++t)
     if (((rows >> (t / 3)) & 1u) && ((cols >> (t % 3)) & 1u)) a.tapmask |= 1u << t;
   return conv_dispatch(a, B, Cin, 9, 1, st);
+}
+
+// The same gradient in ONE launch (the form the trainer uses): grad_out is staged once per workgroup and feeds the four
+// parity classes' accumulators, tap by tap (kernel template IG2); the two column classes leave as one float2 per pixel.
+//   grad_in = (residual ? residual : 0) + conv_transpose2d(grad_out, w, stride 2, pad 1)   cropped to H x W
+// wperm_t: cp_conv_mfma_prepare(w, Cin := Cout of the convolution, Cout := its Cin, taps 9, transposed = 6).
+int cp_conv3x3_s2_input_grad(const float* grad_out, const void* wperm_t, const float* residual, float* grad_in, int32_t B,
+                             int32_t Cin, int32_t H, int32_t W, int32_t Cout, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  CP_CHECK_ARG(grad_out && wperm_t && grad_in && B >= 1 && Cin >= 1 && Cout >= 1 && H >= 1 && W >= 1);
+  const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+  if (!cp_conv3x3_mfma_supported(Cout, Cin, Ho, Wo) || (long long)Cin * H * W * 4 >= 0x7FFFFFF0ll) return CP_EUNSUPPORTED;
+  CvArgs a;
+  for (int i = 0; i < MAXSRC; ++i) {
+    a.xsrc[i] = i == 0 ? grad_out : nullptr;
+    a.csrc[i] = i == 0 ? Cout : 0;
+  }
+  a.wp = (const bf16x8*)wperm_t;
+  a.bias = nullptr; a.res = residual; a.out = grad_in;
+  a.Cin = Cout; a.H = Ho; a.W = Wo; a.Cout = Cin;
+  a.Ho = Ho; a.Wo = Wo;                                      // the launch's grid: one point per grad_out pixel
+  a.nchunk = (Cout + KC - 1) / KC;
+  a.tiles_x = (Wo + TW - 1) / TW;
+  a.relu = 0;
+  a.os = 2; a.oy = 0; a.ox = 0; a.Hf = H; a.Wf = W;
+  a.tapmask = 0x1FFu;
+  auto wgs = [&](int mt, int th) { return (long long)a.tiles_x * ((Ho + th - 1) / th) * B * ((Cin + 16 * mt - 1) / (16 * mt)); };
+  auto launch = [&](auto kernel, int mt, int th) {
+    a.ncot = (Cin + 16 * mt - 1) / (16 * mt);
+    hipLaunchKernelGGL(kernel, dim3(a.tiles_x * ((Ho + th - 1) / th) * a.ncot, B), dim3(256), 0, st, a);
+  };
+  if (Cin > 32 && wgs(4, 4) >= 448) launch(conv_mfma_kernel<4, 1, 9, 1, 1, true>, 4, 4);
+  else if (wgs(2, 8) >= 320) launch(conv_mfma_kernel<2, 2, 9, 1, 1, true>, 2, 8);
+  else launch(conv_mfma_kernel<2, 1, 9, 1, 1, true>, 2, 4);
+  return cp_launch_status();
 }
 
 int cp_conv_mfma_forward(const float* const* xs, const int32_t* cs, int32_t nsrc, const void* wperm, const float* bias,

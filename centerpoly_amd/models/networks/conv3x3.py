@@ -135,8 +135,8 @@ def conv3x3_infer(x, owner, w, bias=None, residual=None, relu=False, conv=None, 
 
 
 def s2_input_grad(xshape, weight, go):
-    """Input gradient of a 3x3 / stride 2 / pad 1 convolution: four parity-class launches of the MFMA convolution over
-    grad_out (cp_conv3x3_s2_input_grad_class); None where the kernel does not take the shape."""
+    """Input gradient of a 3x3 / stride 2 / pad 1 convolution: one launch of the MFMA convolution over grad_out with
+    the four parity classes' accumulators (cp_conv3x3_s2_input_grad); None where the kernel does not take the shape."""
     L = _C.lib()
     B, cin, H, W = xshape
     cout = weight.shape[0]
@@ -149,11 +149,10 @@ def s2_input_grad(xshape, weight, go):
     gx = torch.empty(xshape, dtype=torch.float32, device=go.device)
     nbytes = L.cp_conv_mfma_weight_bytes(cout, cin, 9)
     end = _C.kernel_timer.start(("conv3x3s2_igrad", cout, cin, Ho, Wo, B)) if _C.kernel_timer is not None else None
-    for cls in range(4):
-        wp = torch.empty(nbytes, dtype=torch.uint8, device=go.device)
-        _C.check(L.cp_conv_mfma_prepare(_C.ptr(weight), cout, cin, 9, 2 + cls, _C.ptr(wp), _C.stream()), "cp_conv_mfma_prepare")
-        _C.check(L.cp_conv3x3_s2_input_grad_class(_C.ptr(go), _C.ptr(wp), _C.ptr(gx), B, cin, H, W, cout, cls >> 1, cls & 1,
-                                                  _C.stream()), "cp_conv3x3_s2_input_grad_class")
+    wp = torch.empty(nbytes, dtype=torch.uint8, device=go.device)
+    _C.check(L.cp_conv_mfma_prepare(_C.ptr(weight), cout, cin, 9, 6, _C.ptr(wp), _C.stream()), "cp_conv_mfma_prepare")
+    _C.check(L.cp_conv3x3_s2_input_grad(_C.ptr(go), _C.ptr(wp), None, _C.ptr(gx), B, cin, H, W, cout, _C.stream()),
+             "cp_conv3x3_s2_input_grad")
     if end is not None:
         end.record()
     return gx

@@ -258,6 +258,13 @@ int cp_conv_mfma_forward_strided(const float* const* xs, const int32_t* cs, int3
  *   grad_out [B][Cout][(H - 1) / 2 + 1][(W - 1) / 2 + 1] -> grad_in [B][Cin][H][W] */
 int cp_conv3x3_s2_input_grad_class(const float* grad_out, const void* wperm_class, float* grad_in, int32_t B, int32_t Cin,
                                    int32_t H, int32_t W, int32_t Cout, int32_t py, int32_t px, void* stream);
+/* The same gradient in ONE launch (what the trainer calls): grad_out is staged once per workgroup and feeds the four
+ * parity classes' accumulators tap by tap -- the matrix cores do exactly the forward's flops, grad_out is read once:
+ *   grad_in = (residual ? residual : 0) + conv_transpose2d(grad_out, weight, stride 2, pad 1) cropped to H x W
+ *   wperm_t  cp_conv_mfma_prepare(weight [Cout][Cin][3][3], Cin := Cout, Cout := Cin, taps 9, transposed = 6)
+ *   residual [B][Cin][H][W] or NULL (may be grad_in itself: every element is read, then written, by the same lane) */
+int cp_conv3x3_s2_input_grad(const float* grad_out, const void* wperm_t, const float* residual, float* grad_in, int32_t B,
+                             int32_t Cin, int32_t H, int32_t W, int32_t Cout, void* stream);
 
 /* Weight gradient of the same convolution, same arithmetic (what the reference gets from cuDNN's backward-filter):
  *   gw[co][ci][ky][kx] += sum_{b,y,x} go[b][co][y][x] * x[b][ci][y - 1 + ky][x - 1 + kx]

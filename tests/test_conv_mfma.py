@@ -335,8 +335,8 @@ def test_stride_2_pointwise_forward(shape):
                                    (1, 27, 64, 12, 130), (4, 32, 64, 128, 256)],
                          ids=["32->64", "odd map", "128->256", "256->512", "ragged channels", "level2 size / 4"])
 def test_stride_2_input_gradient(shape):
-    """cp_conv3x3_s2_input_grad_class: the four parity classes of the input gradient of a 3x3 / stride 2 / pad 1
-    convolution against torch.nn.grad.conv2d_input in float64; every element of grad_in written (NaN prefill)."""
+    """cp_conv3x3_s2_input_grad_class / cp_conv3x3_s2_input_grad: the input gradient of a 3x3 / stride 2 / pad 1
+    convolution (per parity class, and all four in one launch) against torch.nn.grad.conv2d_input in float64; every element of grad_in written (NaN prefill)."""
     B, ci, co, H, W = shape
     L = _C.lib()
     Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
@@ -348,6 +348,16 @@ def test_stride_2_input_gradient(shape):
         _C.check(L.cp_conv3x3_s2_input_grad_class(P(go), P(wp), P(gx), B, ci, H, W, co, cls >> 1, cls & 1, _C.stream()), "igrad")
     ref = torch.nn.grad.conv2d_input((B, ci, H, W), w.double(), go.double(), stride=2, padding=1)
     assert torch.isfinite(gx).all() and _rel(gx, ref) <= TOL
+    # the one-launch form (four class accumulators over one staged grad_out tile), alone and onto a residual in place
+    wp = torch.empty(L.cp_conv_mfma_weight_bytes(co, ci, 9), dtype=torch.uint8, device=DEV)
+    _C.check(L.cp_conv_mfma_prepare(P(w), co, ci, 9, 6, P(wp), _C.stream()), "prepare")
+    g1 = torch.full((B, ci, H, W), float("nan"), device=DEV)
+    _C.check(L.cp_conv3x3_s2_input_grad(P(go), P(wp), None, P(g1), B, ci, H, W, co, _C.stream()), "igrad one launch")
+    assert torch.isfinite(g1).all() and _rel(g1, ref) <= TOL
+    res = _t("s2res%s" % (shape,), (B, ci, H, W))
+    g2 = res.clone()
+    _C.check(L.cp_conv3x3_s2_input_grad(P(go), P(wp), P(g2), P(g2), B, ci, H, W, co, _C.stream()), "igrad + residual")
+    assert _rel(g2, ref + res.double()) <= TOL
 
 
 def test_stride_2_autograd_wrapper():

@@ -1,0 +1,24 @@
+import torch, sys
+sys.path.insert(0, "/root/repo")
+from centerpoly_amd import _C
+L=_C.lib(); P=_C.ptr
+for (B,ci,co,H,W) in [(4,32,64,512,1024),(4,64,128,256,512),(4,128,256,128,256),(4,256,512,64,128),(4,16,32,1024,2048)]:
+    Ho,Wo=(H-1)//2+1,(W-1)//2+1
+    w=torch.randn(co,ci,3,3,device="cuda")*0.05; go=torch.randn(B,co,Ho,Wo,device="cuda")
+    gx=torch.empty(B,ci,H,W,device="cuda")
+    wp=torch.empty(L.cp_conv_mfma_weight_bytes(co,ci,9),dtype=torch.uint8,device="cuda")
+    L.cp_conv_mfma_prepare(P(w),co,ci,9,6,P(wp),_C.stream())
+    wps=[]
+    for c in range(4):
+        q=torch.empty_like(wp); L.cp_conv_mfma_prepare(P(w),co,ci,9,2+c,P(q),_C.stream()); wps.append(q)
+    def one(): L.cp_conv3x3_s2_input_grad(P(go),P(wp),None,P(gx),B,ci,H,W,co,_C.stream())
+    def four():
+        for c in range(4): L.cp_conv3x3_s2_input_grad_class(P(go),P(wps[c]),P(gx),B,ci,H,W,co,c>>1,c&1,_C.stream())
+    def lib(): return torch.nn.grad.conv2d_input((B,ci,H,W),w,go,stride=2,padding=1)
+    for name,f in (("one",one),("four",four),("lib",lib)):
+        for _ in range(3): f()
+        torch.cuda.synchronize(); e0=torch.cuda.Event(enable_timing=True); e1=torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20): f()
+        e1.record(); torch.cuda.synchronize()
+        print((B,ci,co,H,W), name, "%.1f us" % (e0.elapsed_time(e1)*50), flush=True)
