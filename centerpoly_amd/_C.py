@@ -61,7 +61,7 @@ _SIGNATURES = {
     "cp_bn_workspace_bytes": (c_size_t, [c_int32, c_int32, c_int64]),
     "cp_bn_act_forward_train": (c_int32, [_P] * 9 + [c_float, c_float, c_int32, c_int32, c_int32, c_int64,
                                                     _P, c_size_t, _P]),
-    "cp_bn_act_backward": (c_int32, [_P] * 6 + [c_int32] + [_P] * 4 + [c_int32, c_int32, c_int64, _P,
+    "cp_bn_act_backward": (c_int32, [_P] * 7 + [c_int32] + [_P] * 4 + [c_int32, c_int32, c_int64, _P,
                                                                        c_size_t, _P]),
     "cp_bias_act_inplace": (c_int32, [_P, _P, _P, c_int32, c_int32, c_int64, c_int32, _P]),
     "cp_channel_sum_accumulate": (c_int32, [_P, _P, c_int32, c_int32, c_int64, _P]),
@@ -159,6 +159,41 @@ def stream():
 
 def workspace(nbytes, device):
     return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
+
+
+class _ZeroPool(object):
+    """Zero-initialised accumulators (the weight / bias gradients the kernels ADD into) carved out of one zero-filled
+    block: one fill kernel per BLOCK bytes handed out instead of one per tensor (the training step asks for ~190 of
+    them, most a few KB -- each a launch of its own).  A block is never reused: a fresh one is allocated when the
+    current one is used up, and the caching allocator recycles a block only once every tensor carved from it has died,
+    so a gradient that outlives the step keeps its memory."""
+    BLOCK = 64 << 20
+
+    def __init__(self):
+        self.block, self.off, self.key = None, 0, None
+
+    def take(self, shape, device):
+        n = 1
+        for d in shape:
+            n *= int(d)
+        nbytes = (n * 4 + 255) // 256 * 256
+        if nbytes > self.BLOCK // 8 or n == 0:
+            return torch.zeros(tuple(shape), dtype=torch.float32, device=device)
+        key = (torch.device(device), torch.cuda.current_stream(device).cuda_stream)
+        if self.block is None or self.key != key or self.off + nbytes > self.BLOCK:
+            self.block = torch.zeros(self.BLOCK // 4, dtype=torch.float32, device=device)
+            self.off, self.key = 0, key
+        t = self.block[self.off // 4: self.off // 4 + n].view(tuple(shape))
+        self.off += nbytes
+        return t
+
+
+_zero_pool = _ZeroPool()
+
+
+def zeros(shape, device):
+    """float32 zeros on a HIP device for a kernel to accumulate into (see _ZeroPool)."""
+    return _zero_pool.take(shape, device)
 
 
 class _NoEvent(object):

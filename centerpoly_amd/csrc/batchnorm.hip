@@ -150,15 +150,22 @@ __global__ __launch_bounds__(THREADS) void bn_apply_kernel(const float* __restri
 }
 
 // backward reduction: partial (sum g, sum g * xhat), g = gy * [y > 0] when relu
+// RECOMP (ReLU without a residual): y is not read -- [y > 0] is the sign of x * sc + sh, the very expression (same
+// operands, same contraction) the forward kernel evaluated, so the mask is bit-identical at a third less traffic.
+template <bool RECOMP>
 __global__ __launch_bounds__(THREADS) void bn_bwd_reduce_kernel(const float* __restrict__ x,
                                                                 const float* __restrict__ y,
                                                                 const float* __restrict__ gy, BnDims d,
                                                                 const float* __restrict__ mean,
                                                                 const float* __restrict__ invstd,
+                                                                const float* __restrict__ w,
+                                                                const float* __restrict__ bias,
                                                                 int relu, double* __restrict__ partial) {
   const int seg = blockIdx.x, c = blockIdx.y, b = blockIdx.z;
   const long long base = ((long long)b * d.C + c) * d.HW;
   const float m = mean[c], is = invstd[c];
+  const float sc = is * (w ? w[c] : 1.f);
+  const float sh = (bias ? bias[c] : 0.f) - m * sc;
   const long long i0 = (long long)seg * SEG, i1 = min(d.HW, i0 + SEG);
   float s = 0.f, q = 0.f;
   if ((d.HW & 3) == 0) {
@@ -169,7 +176,12 @@ __global__ __launch_bounds__(THREADS) void bn_bwd_reduce_kernel(const float* __r
       const bool ok = i < i1;
       xv[j] = ok ? *reinterpret_cast<const f32x4*>(x + base + i) : f32x4{0.f, 0.f, 0.f, 0.f};
       gv[j] = ok ? *reinterpret_cast<const f32x4*>(gy + base + i) : f32x4{0.f, 0.f, 0.f, 0.f};
-      yv[j] = (ok && relu) ? *reinterpret_cast<const f32x4*>(y + base + i) : f32x4{1.f, 1.f, 1.f, 1.f};
+      if (RECOMP) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) yv[j][k] = ok ? xv[j][k] * sc + sh : 0.f;
+      } else {
+        yv[j] = (ok && relu) ? *reinterpret_cast<const f32x4*>(y + base + i) : f32x4{1.f, 1.f, 1.f, 1.f};
+      }
     }
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
@@ -183,7 +195,7 @@ __global__ __launch_bounds__(THREADS) void bn_bwd_reduce_kernel(const float* __r
   } else {
     for (long long i = i0 + threadIdx.x; i < i1; i += THREADS) {
       float g = gy[base + i];
-      if (relu && !(y[base + i] > 0.f)) g = 0.f;
+      if (relu && !((RECOMP ? x[base + i] * sc + sh : y[base + i]) > 0.f)) g = 0.f;
       s += g;
       q += g * ((x[base + i] - m) * is);
     }
@@ -198,14 +210,17 @@ __global__ __launch_bounds__(THREADS) void bn_bwd_reduce_kernel(const float* __r
 }
 
 // dx = w * invstd * (g - dbeta/N - xhat * dgamma/N);  dres = g
+template <bool RECOMP>
 __global__ __launch_bounds__(THREADS) void bn_bwd_apply_kernel(
     const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ gy, BnDims d,
     const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ w,
-    const double* __restrict__ partial, float* __restrict__ grad_w, float* __restrict__ grad_b, int relu,
-    float* __restrict__ gx, float* __restrict__ gres) {
+    const float* __restrict__ bias, const double* __restrict__ partial, float* __restrict__ grad_w,
+    float* __restrict__ grad_b, int relu, float* __restrict__ gx, float* __restrict__ gres) {
   const int seg = blockIdx.x, c = blockIdx.y, b = blockIdx.z;
   const long long base = ((long long)b * d.C + c) * d.HW;
   const float m = mean[c], is = invstd[c];
+  const float sc = is * (w ? w[c] : 1.f);
+  const float sh = (bias ? bias[c] : 0.f) - m * sc;
   double ds, dq;                                     // (sum g, sum g * xhat) of the channel, finalised here
   channel_sums(partial, d, c, ds, dq);
   if (seg == 0 && b == 0 && threadIdx.x == 0) {
@@ -223,7 +238,12 @@ __global__ __launch_bounds__(THREADS) void bn_bwd_apply_kernel(
       const bool ok = i < i1;
       xv[j] = ok ? *reinterpret_cast<const f32x4*>(x + base + i) : f32x4{0.f, 0.f, 0.f, 0.f};
       gv[j] = ok ? *reinterpret_cast<const f32x4*>(gy + base + i) : f32x4{0.f, 0.f, 0.f, 0.f};
-      yv[j] = (ok && relu) ? *reinterpret_cast<const f32x4*>(y + base + i) : f32x4{1.f, 1.f, 1.f, 1.f};
+      if (RECOMP) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) yv[j][k] = ok ? xv[j][k] * sc + sh : 0.f;
+      } else {
+        yv[j] = (ok && relu) ? *reinterpret_cast<const f32x4*>(y + base + i) : f32x4{1.f, 1.f, 1.f, 1.f};
+      }
     }
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
@@ -241,7 +261,7 @@ __global__ __launch_bounds__(THREADS) void bn_bwd_apply_kernel(
   } else {
     for (long long i = i0 + threadIdx.x; i < i1; i += THREADS) {
       float g = gy[base + i];
-      if (relu && !(y[base + i] > 0.f)) g = 0.f;
+      if (relu && !((RECOMP ? x[base + i] * sc + sh : y[base + i]) > 0.f)) g = 0.f;
       gx[base + i] = k0 * (g - db - (x[base + i] - m) * is * dg);
       if (gres) gres[base + i] = g;
     }
@@ -285,7 +305,7 @@ extern "C" int cp_bn_act_forward_train(const float* x, const float* weight, cons
 }
 
 extern "C" int cp_bn_act_backward(const float* x, const float* y, const float* grad_y,
-                                  const float* weight, const float* save_mean,
+                                  const float* weight, const float* bias, const float* save_mean,
                                   const float* save_invstd, int32_t relu, float* grad_x,
                                   float* grad_residual, float* grad_weight, float* grad_bias,
                                   int32_t B, int32_t C, int64_t HW, void* workspace,
@@ -293,14 +313,24 @@ extern "C" int cp_bn_act_backward(const float* x, const float* y, const float* g
   BnDims d;
   const int rc = make_dims(d, B, C, HW);
   if (rc != CP_OK) return rc;
-  CP_CHECK_ARG(x && grad_y && save_mean && save_invstd && grad_x && workspace && (!relu || y));
+  // y == NULL with ReLU (forwards WITHOUT a residual only): the mask is recomputed from x, weight and `bias` (the
+  // forward's, NULL if it had none) -- y is never read
+  const bool recomp = relu && !y;
+  CP_CHECK_ARG(x && grad_y && save_mean && save_invstd && grad_x && workspace && !(recomp && grad_residual));
   if (workspace_bytes < cp_bn_workspace_bytes(B, C, HW)) return CP_EWORKSPACE;
   hipStream_t st = (hipStream_t)stream;
   double* partial = (double*)workspace;
   const dim3 grid(d.nseg, C, B);
-  hipLaunchKernelGGL(bn_bwd_reduce_kernel, grid, dim3(THREADS), 0, st, x, y, grad_y, d, save_mean,
-                     save_invstd, relu, partial);
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, grid, dim3(THREADS), 0, st, x, y, grad_y, d, save_mean,
-                     save_invstd, weight, partial, grad_weight, grad_bias, relu, grad_x, grad_residual);
+  if (recomp) {
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel<true>, grid, dim3(THREADS), 0, st, x, y, grad_y, d, save_mean, save_invstd,
+                       weight, bias, relu, partial);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, grid, dim3(THREADS), 0, st, x, y, grad_y, d, save_mean, save_invstd,
+                       weight, bias, partial, grad_weight, grad_bias, relu, grad_x, grad_residual);
+  } else {
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel<false>, grid, dim3(THREADS), 0, st, x, y, grad_y, d, save_mean, save_invstd,
+                       weight, bias, relu, partial);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, grid, dim3(THREADS), 0, st, x, y, grad_y, d, save_mean, save_invstd,
+                       weight, bias, partial, grad_weight, grad_bias, relu, grad_x, grad_residual);
+  }
   return cp_launch_status();
 }

@@ -28,6 +28,14 @@ namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
+#ifndef CP_CVABL
+#define CP_CVABL 0                  // timing-only ablation bits (tools/probe_conv_ablate.py; results wrong by construction):
+#endif                              // 1 weight fragments never re-loaded, 2 no staging loads, 4 no B ds_reads, 8 no MFMA, 16 no staging at all
+#ifdef CP_CVSTAMP                   // diagnostic build (tools/probe_conv_stamp.py): s_memtime stamps of wave 0 over out[]
+#define CVSTAMP(i) do { if ((i) < 16) stamp[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define CVSTAMP(i) do { } while (0)
+#endif
 constexpr int KC = 32;              // input channels per k-step
 constexpr int TW = 32;              // tile width (pixels)
 constexpr unsigned OOB = 0xFFFFFFF0u;
@@ -108,6 +116,12 @@ template <int MT, int RW, int TAPS, int KS = 1, int ST = 1, bool IG2 = false>
 __global__ __launch_bounds__(256 * KS, KS > 1 ? 4 : 2) void conv_mfma_kernel(CvArgs a) {
   static_assert(!IG2 || (TAPS == 9 && KS == 1 && ST == 1), "IG2: 3x3, stride-1 staging, no split-K");
   constexpr int NCLS = IG2 ? 4 : 1;
+#ifdef CP_CVSTAMP
+  unsigned long long stamp[16];
+  const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();
+  int sti = 1;
+#endif
+  CVSTAMP(0);
   constexpr int S = TAPS == 1 ? 1 : ST;          // stride of the staged tile's geometry
   constexpr int SUB = TAPS == 1 ? ST : 1;        // 1x1: input subsampling folded into the staging addresses
   constexpr int HALO = TAPS == 9 ? 1 : 0, LW = S * TW + (TAPS == 9 ? 3 : 1) - S;
@@ -161,52 +175,79 @@ __global__ __launch_bounds__(256 * KS, KS > 1 ? 4 : 2) void conv_mfma_kernel(CvA
   const int bbase = (g * LH + S * wid * RW) * LW + S * c;
 
   int src = 0, src_c0 = 0;                                    // source tensor of the current chunk, its first channel
+  // staging of one chunk: `load` issues the unit loads i0 .. i0 + N - 1 into v, `store` splits them into the LDS planes
+  auto load = [&](int chunk, int i0, auto& v) {
+    while (src + 1 < MAXSRC && chunk * KC >= src_c0 + a.csrc[src] && a.csrc[src + 1] > 0) {
+      src_c0 += a.csrc[src];
+      ++src;
+    }
+    const int cs = a.csrc[src];
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.xsrc[src] + (long long)b * cs * HW), 0, (int)((unsigned)cs * (unsigned)HW * 4u), 0x00020000);
+    const unsigned cb = (unsigned)(chunk * KC - src_c0) * cstep;
+    constexpr int N = sizeof(v) / sizeof(v[0]);
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      const unsigned o = (i0 + i >= ITERS || soff[(i0 + i) % ITERS] == OOB) ? OOB : soff[(i0 + i) % ITERS] + cb;
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        v[i][j] = (CP_CVABL & 2) ? (float)(o + j) : __builtin_bit_cast(
+            float, __builtin_amdgcn_raw_buffer_load_b32(rs_x, o == OOB ? OOB : o + j * cstep, 0, 0));
+    }
+  };
+  auto store = [&](int i0, auto& v) {
+    constexpr int N = sizeof(v) / sizeof(v[0]);
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      const int u = tid + (i0 + i) * 256;
+      if (i0 + i < ITERS && u < UNITS) {
+        bf16x8 h, l;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const __bf16 hh = (__bf16)v[i][j];
+          h[j] = hh;
+          l[j] = (__bf16)(v[i][j] - (float)hh);
+        }
+        Xs[u] = h;
+        Xs[PLANE + u] = l;
+      }
+    }
+  };
+  auto bread = [&](int tap, bf16x8 (&bh)[NT], bf16x8 (&bl)[NT]) {
+    const int dy = IG2 ? (tap / 3 == 0 ? 2 : 1) : tap / 3, dx = IG2 ? (tap % 3 == 0 ? 2 : 1) : tap % 3;
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+      const int idx = bbase + (S * (n >> 1) + dy) * LW + S * (n & 1) * 16 + dx;
+      bh[n] = (CP_CVABL & 4) ? af[n % MT][0] : Xs[idx];
+      bl[n] = (CP_CVABL & 4) ? af[n % MT][1] : Xs[PLANE + idx];
+    }
+  };
+
   for (int chunk = grp; chunk - grp < a.nchunk; chunk += KS) {
     const bool active = chunk < a.nchunk;                     // (wave-uniform; every wave takes every barrier)
     __syncthreads();                                          // the previous chunk's fragments have been read
-    if (active) {
-      while (src + 1 < MAXSRC && chunk * KC >= src_c0 + a.csrc[src] && a.csrc[src + 1] > 0) {
-        src_c0 += a.csrc[src];
-        ++src;
-      }
-      const int cs = a.csrc[src];
-      const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
-          const_cast<float*>(a.xsrc[src] + (long long)b * cs * HW), 0, (int)((unsigned)cs * (unsigned)HW * 4u), 0x00020000);
-      const unsigned cb = (unsigned)(chunk * KC - src_c0) * cstep;
+#ifdef CP_CVSTAMP
+    CVSTAMP(sti); ++sti;
+#endif
+    if (active && !(CP_CVABL & 16)) {
 #pragma unroll
       for (int i0 = 0; i0 < ITERS; i0 += SB) {                // batches of SB units: 8 SB loads in flight per thread
         float v[SB][8];
-#pragma unroll
-        for (int i = 0; i < SB; ++i) {
-          const unsigned o = (i0 + i >= ITERS || soff[(i0 + i) % ITERS] == OOB) ? OOB : soff[(i0 + i) % ITERS] + cb;
-#pragma unroll
-          for (int j = 0; j < 8; ++j)
-            v[i][j] = __builtin_bit_cast(
-                float, __builtin_amdgcn_raw_buffer_load_b32(rs_x, o == OOB ? OOB : o + j * cstep, 0, 0));
-        }
-#pragma unroll
-        for (int i = 0; i < SB; ++i) {
-          const int u = tid + (i0 + i) * 256;
-          if (i0 + i < ITERS && u < UNITS) {
-            bf16x8 h, l;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-              const __bf16 hh = (__bf16)v[i][j];
-              h[j] = hh;
-              l[j] = (__bf16)(v[i][j] - (float)hh);
-            }
-            Xs[u] = h;
-            Xs[PLANE + u] = l;
-          }
-        }
+        load(chunk, i0, v);
+        store(i0, v);
       }
     }
+#ifdef CP_CVSTAMP
+    CVSTAMP(sti); ++sti;
+#endif
     __syncthreads();
+#ifdef CP_CVSTAMP
+    CVSTAMP(sti); ++sti;
+#endif
     if (!active) continue;
 
 #pragma unroll
     for (int tap = 0; tap < TAPS; ++tap) {
-      const int dy = IG2 ? (tap / 3 == 0 ? 2 : 1) : tap / 3, dx = IG2 ? (tap % 3 == 0 ? 2 : 1) : tap % 3;
       const int cls = IG2 ? (tap / 3 != 1) * 2 + (tap % 3 != 1) : 0;
       const bool tap_on = (a.tapmask >> tap) & 1u;             // (wave-uniform; stride-2 input gradient: 1, 2 or 4 of 9)
       // next tap's (or this group's next chunk's first) weight fragments; past the end: re-read the last
@@ -217,23 +258,22 @@ __global__ __launch_bounds__(256 * KS, KS > 1 ? 4 : 2) void conv_mfma_kernel(CvA
         const bf16x8* nq = wq + (long long)(nfrag * 2) * 64;
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
-          an[m][0] = nq[m * tstride];
-          an[m][1] = nq[m * tstride + 64];
+          an[m][0] = (CP_CVABL & 1) ? af[m][0] : nq[m * tstride];
+          an[m][1] = (CP_CVABL & 1) ? af[m][1] : nq[m * tstride + 64];
         }
       }
       if (tap_on) {
         bf16x8 bh[NT], bl[NT];
-#pragma unroll
-        for (int n = 0; n < NT; ++n) {
-          const int idx = bbase + (S * (n >> 1) + dy) * LW + S * (n & 1) * 16 + dx;
-          bh[n] = Xs[idx];
-          bl[n] = Xs[PLANE + idx];
-        }
+        bread(tap, bh, bl);
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
           for (int n = 0; n < NT; ++n) {
             f32x4& d = accs[cls][m][n];
+            if (CP_CVABL & 8) {
+              d[0] += (float)bh[n][0] * (float)af[m][0][0] + (float)bl[n][1] * (float)af[m][1][1];
+              continue;
+            }
             d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[m][0], bh[n], d, 0, 0, 0);
             d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[m][0], bl[n], d, 0, 0, 0);
             d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[m][1], bh[n], d, 0, 0, 0);
@@ -246,6 +286,9 @@ __global__ __launch_bounds__(256 * KS, KS > 1 ? 4 : 2) void conv_mfma_kernel(CvA
       }
       __builtin_amdgcn_sched_barrier(0);                      // keep the taps' fragment reads from piling up
     }
+#ifdef CP_CVSTAMP
+    CVSTAMP(sti); ++sti;
+#endif
   }
 
   if (KS > 1) {                                               // partial sums of groups 1 .. KS-1 -> LDS -> group 0
@@ -326,6 +369,18 @@ __global__ __launch_bounds__(256 * KS, KS > 1 ? 4 : 2) void conv_mfma_kernel(CvA
       }
     }
   }
+#ifdef CP_CVSTAMP
+  {
+    const unsigned long long rt1 = __builtin_amdgcn_s_memrealtime();
+    if (tid == 0) {
+      float* o = a.out + (long long)gridDim.y * a.Cout * a.Hf * a.Wf + ((long long)b * gridDim.x + blockIdx.x) * 16;   // past the output
+      for (int i = 0; i + 1 < 14; ++i) o[i] = i + 1 < sti ? (float)(stamp[i + 1] - stamp[i]) : 0.f;
+      o[13] = (float)sti;
+      o[14] = (float)(rt1 - rt0);          // 100 MHz ticks
+      o[15] = (float)(rt0 & 0xffffff);
+    }
+  }
+#endif
 }
 
 int tiles16(int Cout) { return (Cout + 63) / 64 * 4; }             // 16-row weight tiles, padded to whole groups of 4

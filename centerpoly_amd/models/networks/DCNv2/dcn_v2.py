@@ -143,8 +143,8 @@ class _DCNv2Function(torch.autograd.Function):
         grad_out = grad_out.contiguous()
         gx = torch.empty_like(x)                         # (overwritten: the library zero-fills it itself)
         gom = torch.empty_like(om)
-        gw = torch.zeros_like(weight)
-        gb = torch.zeros((s.Cout,), dtype=torch.float32, device=x.device)
+        gw = _C.zeros(weight.shape, weight.device)
+        gb = _C.zeros((s.Cout,), x.device)
         bs = 3 * K * Ho * Wo
         off_m = 4 * 2 * K * Ho * Wo
         ws = _C.workspace(L.cp_dcn_v2_backward_workspace_bytes(s), x.device)
@@ -183,8 +183,8 @@ def _dcn_backward(x, om, weight, grad_out, has_bias):
     grad_out = grad_out.contiguous()
     gx = torch.empty_like(x)                             # (overwritten: the library zero-fills it itself)
     gom = torch.empty_like(om)
-    gw = torch.zeros_like(weight)
-    gb = torch.zeros((s.Cout,), dtype=torch.float32, device=x.device)
+    gw = _C.zeros(weight.shape, weight.device)
+    gb = _C.zeros((s.Cout,), x.device)
     bs = 3 * K * Ho * Wo
     off_m = 4 * 2 * K * Ho * Wo
     ws = _C.workspace(L.cp_dcn_v2_backward_workspace_bytes(s), x.device)
@@ -241,7 +241,7 @@ class _DCNModuleFunction(torch.autograd.Function):
         gx, gom, gw, gb = _dcn_backward(x, om, weight, grad_out, ctx.has_bias)
         B, C, H, W = gom.shape
         L = _C.lib()
-        gb_om = torch.zeros(C, dtype=torch.float32, device=gom.device)
+        gb_om = _C.zeros((C,), gom.device)
         _C.check(L.cp_channel_sum_accumulate(_C.ptr(gom), _C.ptr(gb_om), B, C, H * W, _C.stream()), "cp_channel_sum_accumulate")
         _, gw_om = conv3x3.grads(x, om_weight, gom, want_x=False, want_w=True)
         cin = om_weight.shape[1]
@@ -267,7 +267,7 @@ class _ConvBias(torch.autograd.Function):
     def backward(ctx, go):
         go = go.contiguous()
         B, C, H, W = go.shape
-        gb = torch.zeros(C, dtype=torch.float32, device=go.device)
+        gb = _C.zeros((C,), go.device)
         _C.check(_C.lib().cp_channel_sum_accumulate(_C.ptr(go), _C.ptr(gb), B, C, H * W, _C.stream()),
                  "cp_channel_sum_accumulate")
         return go, gb

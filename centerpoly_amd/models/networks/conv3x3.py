@@ -206,7 +206,7 @@ def grads(x, weight, go, want_x=True, want_w=True, min_k=1):
             gx = torch.nn.grad.conv2d_input(x.shape, weight, go, padding=pad)
     if want_w:
         if _WGRAD and L.cp_conv3x3_mfma_wgrad_supported(cin, cout, H, W):
-            gw = torch.zeros_like(weight)
+            gw = _C.zeros(weight.shape, weight.device)
             tag = "conv3x3_wgrad" if taps == 9 else "conv1x1_wgrad"
             end = _C.kernel_timer.start((tag, cin, cout, H, W, B)) if _C.kernel_timer is not None else None
             _C.check(L.cp_conv_mfma_wgrad(_C.ptr(x), _C.ptr(go), _C.ptr(gw), B, cin, H, W, cout, taps, _C.stream()),
@@ -237,7 +237,7 @@ class _ConvBiasActFn(torch.autograd.Function):
         go = go.contiguous()
         B, C, H, W = go.shape
         L = _C.lib()
-        gb = torch.zeros(C, dtype=torch.float32, device=go.device)
+        gb = _C.zeros((C,), go.device)
         if ctx.relu:
             g = torch.empty_like(go)
             _C.check(L.cp_bias_relu_backward(_C.ptr(y), _C.ptr(go), _C.ptr(g), _C.ptr(gb), B, C, H * W, _C.stream()),

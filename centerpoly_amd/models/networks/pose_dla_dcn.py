@@ -115,7 +115,7 @@ class _DirectConvFn(torch.autograd.Function):
             if direct_w and L.cp_conv_direct_wgrad_supported(cin, cout, k, stride, pad):
                 # pixel-contraction kernel on the exact f32 MFMA instead of the library's NHWC implicit GEMM behind
                 # two full-resolution layout transposes
-                gw = torch.zeros_like(weight)
+                gw = _C.zeros(weight.shape, weight.device)
                 rc = L.cp_conv_direct_wgrad(_C.ptr(x), _C.ptr(go), _C.ptr(gw), B, cin, H, W, cout, k, stride, pad,
                                             _C.stream())
                 if rc == -2:
@@ -221,7 +221,7 @@ class _BiasRelu(torch.autograd.Function):
         go = go.contiguous()
         B, C, H, W = y.shape
         g = torch.empty_like(go)
-        gb = torch.zeros(C, dtype=torch.float32, device=y.device)
+        gb = _C.zeros((C,), y.device)
         _C.check(_C.lib().cp_bias_relu_backward(_C.ptr(y), _C.ptr(go), _C.ptr(g), _C.ptr(gb), B, C, H * W,
                                                 _C.stream()), "cp_bias_relu_backward")
         return g, gb
@@ -258,13 +258,15 @@ class _BnAct(torch.autograd.Function):
                                        _C.ptr(running_var), momentum, eps, 1 if relu else 0, B, C,
                                        H * W, _C.ptr(ws), ws.numel(), _C.stream())
         _C.check(rc, "cp_bn_act_forward_train")
-        ctx.save_for_backward(x, y, weight, mean, invstd)
+        # ReLU without a residual: the backward recomputes the mask from x (y is neither saved here nor read there)
+        recompute = relu and residual is None
+        ctx.save_for_backward(x, None if recompute else y, weight, bias, mean, invstd)
         ctx.cfg = (relu, residual is not None)
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        x, y, weight, mean, invstd = ctx.saved_tensors
+        x, y, weight, bias, mean, invstd = ctx.saved_tensors
         relu, has_res = ctx.cfg
         L = _C.lib()
         gy = gy.contiguous()
@@ -274,7 +276,7 @@ class _BnAct(torch.autograd.Function):
         gw = torch.empty(C, dtype=torch.float32, device=x.device)       # overwritten by the kernel
         gb = torch.empty(C, dtype=torch.float32, device=x.device)
         ws = _C.workspace(L.cp_bn_workspace_bytes(B, C, H * W), x.device)
-        rc = L.cp_bn_act_backward(_C.ptr(x), _C.ptr(y), _C.ptr(gy), _C.ptr(weight), _C.ptr(mean),
+        rc = L.cp_bn_act_backward(_C.ptr(x), _C.ptr(y), _C.ptr(gy), _C.ptr(weight), _C.ptr(bias), _C.ptr(mean),
                                   _C.ptr(invstd), 1 if relu else 0, _C.ptr(gx), _C.ptr(gres), _C.ptr(gw),
                                   _C.ptr(gb), B, C, H * W, _C.ptr(ws), ws.numel(), _C.stream())
         _C.check(rc, "cp_bn_act_backward")
@@ -554,7 +556,7 @@ class _DepthwiseUpAdd(torch.autograd.Function):
         go = go.contiguous()
         B, C, H, W = x.shape
         gx = torch.empty_like(x)
-        gw = torch.zeros_like(weight)
+        gw = _C.zeros(weight.shape, weight.device)
         rc = L.cp_depthwise_up_backward(_C.ptr(x), _C.ptr(weight), _C.ptr(go), _C.ptr(gx), _C.ptr(gw),
                                         B, C, H, W, ctx.f, _C.stream())
         _C.check(rc, "cp_depthwise_up_backward")

@@ -396,14 +396,16 @@ int cp_polydet_targets(const cp_target_shape* s, const double* bbox_xywh, const 
  * (src/lib/models/networks/pose_dla_dcn.py:32-60,148-166,266-277,347-359) in training.
  * x, y, residual and their gradients: fp32 [B,C,H,W], HW = H x W; weight, bias, running and
  * saved statistics: [C].  backward: grad_weight / grad_bias are OVERWRITTEN; grad_residual (may be NULL) receives
- * the post-activation gradient; workspace from cp_bn_workspace_bytes. */
+ * the post-activation gradient; workspace from cp_bn_workspace_bytes.  `bias` is the forward's bias (NULL if it had none);
+ * with relu and NO residual in the forward, pass y = NULL: the ReLU mask [y > 0] is then recomputed from x (the forward's
+ * own expression, bit-identical) and y is not read -- a third less traffic (y = NULL with grad_residual: CP_EINVAL). */
 size_t cp_bn_workspace_bytes(int32_t B, int32_t C, int64_t HW);
 int cp_bn_act_forward_train(const float* x, const float* weight, const float* bias,
                             const float* residual, float* y, float* save_mean, float* save_invstd,
                             float* running_mean, float* running_var, float momentum, float eps,
                             int32_t relu, int32_t B, int32_t C, int64_t HW, void* workspace,
                             size_t workspace_bytes, void* stream);
-int cp_bn_act_backward(const float* x, const float* y, const float* grad_y, const float* weight,
+int cp_bn_act_backward(const float* x, const float* y, const float* grad_y, const float* weight, const float* bias,
                        const float* save_mean, const float* save_invstd, int32_t relu, float* grad_x,
                        float* grad_residual, float* grad_weight, float* grad_bias, int32_t B,
                        int32_t C, int64_t HW, void* workspace, size_t workspace_bytes, void* stream);
