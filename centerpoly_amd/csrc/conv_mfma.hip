@@ -44,13 +44,8 @@ constexpr unsigned OOB = 0xFFFFFFF0u;
 //   half(hl) of Wsrc[m = ct * 16 + (lane & 15)][k = chunk * 32 + 8 (lane >> 4) + j][tap]        (ct: 16-row tile)
 // taps = 9 (3x3) or 1 (1x1).  Wsrc = W ([M][K][taps]) or, transposed (input gradient):
 // Wsrc[m][k][tap] = W[k][m][taps - 1 - tap] with W = [K][M][taps].
-// transposed = 2 + 2 py + px (stride-2 input gradient, parity class (py, px) of the output rows / columns; W = [K][M][3][3]):
-// the class's gradient is a stride-1 convolution of grad_out whose tap (ty, tx) (rows i - 1 + ty of grad_out) carries
-// W[k][m][ky][kx] with ky = class_tap(py, ty): py = 0: ty 1 -> ky 1;  py = 1: ty 1 -> ky 2, ty 2 -> ky 0; other taps 0.
 // transposed = 6 (the one-pass stride-2 input gradient, IG2): Wsrc[m][k][tap] = W[k][m][tap].
 // Rows past M (the tile count is rounded up to a multiple of 4) and k past K are zero.
-__device__ __forceinline__ int s2_class_tap(int par, int t) { return par == 0 ? (t == 1 ? 1 : -1) : (t == 1 ? 2 : (t == 2 ? 0 : -1)); }
-
 __global__ __launch_bounds__(256) void conv_mfma_wperm_kernel(const float* __restrict__ w, bf16x8* __restrict__ wp, int M,
                                                               int K, int nchunk, int taps, int transposed, int total) {
   const int e = blockIdx.x * 256 + threadIdx.x;
@@ -71,9 +66,6 @@ __global__ __launch_bounds__(256) void conv_mfma_wperm_kernel(const float* __res
     if (m < M && k < K) {
       if (transposed == 6) {                                   // IG2: transposed, taps in place
         v = w[((long long)k * M + m) * 9 + tap];
-      } else if (transposed >= 2) {
-        const int ky = s2_class_tap((transposed - 2) >> 1, tap / 3), kx = s2_class_tap((transposed - 2) & 1, tap % 3);
-        if (ky >= 0 && kx >= 0) v = w[((long long)k * M + m) * 9 + ky * 3 + kx];
       } else {
         v = transposed ? w[((long long)k * M + m) * taps + (taps - 1 - tap)] : w[((long long)m * K + k) * taps + tap];
       }
@@ -93,10 +85,7 @@ struct CvArgs {
   const float* res;       // same shape as out, or null
   float* out;
   int Cin, H, W, Ho, Wo, Cout, nchunk, ncot, tiles_x, relu;   // H, W: input; Ho, Wo: output grid of the launch
-  // output placement: element (y, x) of the launch's grid goes to row os * y + oy, column os * x + ox of a map of
-  // Hf x Wf (plain convolutions: os 1, oy = ox 0, Hf x Wf = Ho x Wo; stride-2 input gradient: one parity class per launch)
-  int os, oy, ox, Hf, Wf;
-  unsigned tapmask;            // taps whose weights are not identically zero (bit = tap index; all ones normally)
+  int Hf, Wf;                  // IG2: the gradient map (element (y, x) of class (py, px) goes to (2 y + py, 2 x + px)); else Ho, Wo
 };
 
 // KS > 1 (deep, small layers whose grid cannot fill the chip -- one wave per SIMD exposes every load latency): the
@@ -249,7 +238,6 @@ __global__ __launch_bounds__(256 * KS, KS > 1 ? 4 : 2) void conv_mfma_kernel(CvA
 #pragma unroll
     for (int tap = 0; tap < TAPS; ++tap) {
       const int cls = IG2 ? (tap / 3 != 1) * 2 + (tap % 3 != 1) : 0;
-      const bool tap_on = (a.tapmask >> tap) & 1u;             // (wave-uniform; stride-2 input gradient: 1, 2 or 4 of 9)
       // next tap's (or this group's next chunk's first) weight fragments; past the end: re-read the last
       bf16x8 an[MT][2];
       {
@@ -262,7 +250,7 @@ __global__ __launch_bounds__(256 * KS, KS > 1 ? 4 : 2) void conv_mfma_kernel(CvA
           an[m][1] = (CP_CVABL & 1) ? af[m][1] : nq[m * tstride + 64];
         }
       }
-      if (tap_on) {
+      {
         bf16x8 bh[NT], bl[NT];
         bread(tap, bh, bl);
 #pragma unroll
@@ -360,7 +348,7 @@ __global__ __launch_bounds__(256 * KS, KS > 1 ? 4 : 2) void conv_mfma_kernel(CvA
       for (int n = 0; n < NT; ++n) {
         const int y = y0 + wid * RW + (n >> 1), x = x0 + (n & 1) * 16 + c;
         if (y < a.Ho && x < a.Wo) {
-          const long long o = (long long)co * HWf + (long long)(a.os * y + a.oy) * a.Wf + (a.os * x + a.ox);
+          const long long o = (long long)co * HWf + (long long)y * a.Wf + x;
           float v = acc[m][n][r] + bv;
           if (rb) v += rb[o];
           if (a.relu) v = fmaxf(v, 0.f);
@@ -491,48 +479,16 @@ int cp_conv_mfma_forward_strided(const float* const* xs, const int32_t* cs, int3
   a.nchunk = (Cin + KC - 1) / KC;
   a.tiles_x = (a.Wo + TW - 1) / TW;
   a.relu = relu;
-  a.os = 1; a.oy = 0; a.ox = 0; a.Hf = a.Ho; a.Wf = a.Wo;
-  a.tapmask = 0x1ffu;
+  a.Hf = a.Ho; a.Wf = a.Wo;
   return conv_dispatch(a, B, Cout, taps, stride, st);
 }
 
-// INPUT GRADIENT of a 3x3 / stride 2 / pad 1 convolution (the first convolution of DLA levels 2-5, pose_dla_dcn.py:38-46;
-// what the reference gets from cuDNN's backward-data), one parity class of the input rows / columns per call:
-//   grad_in[b][ci][2 i + py][2 j + px] = sum_{co} sum_{(ky, kx) in class} w[co][ci][ky][kx] * grad_out[b][co][i + dy(ky)][j + dx(kx)]
-// -- a stride-1 convolution of grad_out with 1, 2, 2 or 4 of the nine taps (no multiplications by inserted zeros; the four
-// classes together do exactly the forward's work) whose results are written to every second row / column of grad_in.
-// wperm_class: cp_conv_mfma_prepare(w, Cin := Cout of the convolution, Cout := its Cin, taps 9, transposed = 2 + 2 py + px).
-// grad_out [B][Cout][Ho][Wo] with Ho = (H - 1) / 2 + 1; grad_in [B][Cin][H][W]: the four calls write every element.
-int cp_conv3x3_s2_input_grad_class(const float* grad_out, const void* wperm_class, float* grad_in, int32_t B, int32_t Cin,
-                                   int32_t H, int32_t W, int32_t Cout, int32_t py, int32_t px, void* stream) {
-  hipStream_t st = (hipStream_t)stream;
-  CP_CHECK_ARG(grad_out && wperm_class && grad_in && B >= 1 && Cin >= 1 && Cout >= 1 && H >= 1 && W >= 1);
-  CP_CHECK_ARG((py == 0 || py == 1) && (px == 0 || px == 1));
-  const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
-  if (!cp_conv3x3_mfma_supported(Cout, Cin, Ho, Wo) || (long long)Cin * H * W * 4 >= 0x7FFFFFF0ll) return CP_EUNSUPPORTED;
-  const int ny = (H - py + 1) / 2, nx = (W - px + 1) / 2;            // rows / columns of this class
-  if (ny <= 0 || nx <= 0) return CP_OK;
-  CvArgs a;
-  for (int i = 0; i < MAXSRC; ++i) {
-    a.xsrc[i] = i == 0 ? grad_out : nullptr;
-    a.csrc[i] = i == 0 ? Cout : 0;
-  }
-  a.wp = (const bf16x8*)wperm_class;
-  a.bias = nullptr; a.res = nullptr; a.out = grad_in;
-  a.Cin = Cout; a.H = Ho; a.W = Wo; a.Cout = Cin;
-  a.Ho = ny; a.Wo = nx;
-  a.nchunk = (Cout + KC - 1) / KC;
-  a.tiles_x = (nx + TW - 1) / TW;
-  a.relu = 0;
-  a.os = 2; a.oy = py; a.ox = px; a.Hf = H; a.Wf = W;
-  const unsigned rows = py ? 0x6u : 0x2u, cols = px ? 0x6u : 0x2u;   // tap rows / columns in use (bit = index 0..2)
-  a.tapmask = 0;
-  for (int t = 0; t < 9; ++t)
-    if (((rows >> (t / 3)) & 1u) && ((cols >> (t % 3)) & 1u)) a.tapmask |= 1u << t;
-  return conv_dispatch(a, B, Cin, 9, 1, st);
-}
-
-// The same gradient in ONE launch (the form the trainer uses): grad_out is staged once per workgroup and feeds the four
+// INPUT GRADIENT of a 3x3 / stride 2 / pad 1 convolution (the first convolution of DLA levels 2-5, pose_dla_dcn.py:32-40;
+// what the reference gets from cuDNN's backward-data):
+//   grad_in[b][ci][2 i + py][2 j + px] = sum_{co} sum_{(ky, kx) in class (py, px)} w[co][ci][ky][kx] * grad_out[b][co][i + dy(ky)][j + dx(kx)]
+// -- per parity class (py, px) of the gradient's rows / columns a stride-1 convolution of grad_out with 1, 2, 2 or 4 of
+// the nine taps (no multiplications by inserted zeros: the four classes together do exactly the forward's work).
+// ONE launch: grad_out is staged once per workgroup and feeds the four
 // parity classes' accumulators, tap by tap (kernel template IG2); the two column classes leave as one float2 per pixel.
 //   grad_in = (residual ? residual : 0) + conv_transpose2d(grad_out, w, stride 2, pad 1)   cropped to H x W
 // wperm_t: cp_conv_mfma_prepare(w, Cin := Cout of the convolution, Cout := its Cin, taps 9, transposed = 6).
@@ -554,8 +510,7 @@ int cp_conv3x3_s2_input_grad(const float* grad_out, const void* wperm_t, const f
   a.nchunk = (Cout + KC - 1) / KC;
   a.tiles_x = (Wo + TW - 1) / TW;
   a.relu = 0;
-  a.os = 2; a.oy = 0; a.ox = 0; a.Hf = H; a.Wf = W;
-  a.tapmask = 0x1FFu;
+  a.Hf = H; a.Wf = W;
   auto wgs = [&](int mt, int th) { return (long long)a.tiles_x * ((Ho + th - 1) / th) * B * ((Cin + 16 * mt - 1) / (16 * mt)); };
   auto launch = [&](auto kernel, int mt, int th) {
     a.ncot = (Cin + 16 * mt - 1) / (16 * mt);

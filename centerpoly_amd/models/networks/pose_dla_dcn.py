@@ -80,7 +80,7 @@ def _conv_direct(x, conv, wb, relu):
 
 class _DirectConvFn(torch.autograd.Function):
     """Training forward of a bias-free convolution of the DLA base through the direct kernel; weight gradient
-    from cp_conv_direct_wgrad, level0's input gradient from the MFMA convolution, level1's from the library."""
+    from cp_conv_direct_wgrad, level0's and level1's input gradients from the MFMA convolution."""
 
     @staticmethod
     def forward(ctx, x, weight, stride, pad):
@@ -107,7 +107,10 @@ class _DirectConvFn(torch.autograd.Function):
             # trip costs 5x more); the weight gradient from the direct kernel below
             gx, gw = conv3x3.grads(x, weight, go, ctx.needs_input_grad[0], ctx.needs_input_grad[1] and not direct_w)
         elif ctx.needs_input_grad[0]:
-            gx = torch.nn.grad.conv2d_input(x.shape, weight, go, stride=stride, padding=pad)
+            if weight.shape[2] == 3 and stride == 2 and pad == 1 and conv3x3.mfma_enabled():
+                gx = conv3x3.s2_input_grad(tuple(x.shape), weight, go)     # level1 (16 -> 32, stride 2): one MFMA launch
+            if gx is None:
+                gx = torch.nn.grad.conv2d_input(x.shape, weight, go, stride=stride, padding=pad)
         if ctx.needs_input_grad[1] and gw is None:
             L = _C.lib()
             B, cin, H, W = x.shape

@@ -250,18 +250,14 @@ int cp_conv_mfma_forward(const float* const* xs, const int32_t* cs, int32_t nsrc
 int cp_conv_mfma_forward_strided(const float* const* xs, const int32_t* cs, int32_t nsrc, const void* wperm,
                                  const float* bias, const float* residual, float* out, int32_t B, int32_t H, int32_t W,
                                  int32_t Cout, int32_t taps, int32_t stride, int32_t relu, void* stream);
-/* Input gradient of a 3x3 / stride 2 / pad 1 convolution (the first convolution of DLA levels 2-5,
- * src/lib/models/networks/pose_dla_dcn.py:38-46; cuDNN's backward-data in the reference), one parity class (py, px) of the
- * input rows / columns per call -- a stride-1 convolution of grad_out with 1, 2, 2 or 4 of the nine taps, written to every
- * second row / column of grad_in; the four calls together write every element and do exactly the forward's work.
- *   wperm_class  cp_conv_mfma_prepare(weight [Cout][Cin][3][3], Cin := Cout, Cout := Cin, taps 9, transposed = 2 + 2 py + px)
- *   grad_out [B][Cout][(H - 1) / 2 + 1][(W - 1) / 2 + 1] -> grad_in [B][Cin][H][W] */
-int cp_conv3x3_s2_input_grad_class(const float* grad_out, const void* wperm_class, float* grad_in, int32_t B, int32_t Cin,
-                                   int32_t H, int32_t W, int32_t Cout, int32_t py, int32_t px, void* stream);
-/* The same gradient in ONE launch (what the trainer calls): grad_out is staged once per workgroup and feeds the four
- * parity classes' accumulators tap by tap -- the matrix cores do exactly the forward's flops, grad_out is read once:
+/* Input gradient of a 3x3 / stride 2 / pad 1 convolution (the first convolution of DLA levels 1-5,
+ * src/lib/models/networks/pose_dla_dcn.py:32-40,236-246; cuDNN's backward-data in the reference) in ONE launch: per parity
+ * class (py, px) of the gradient's rows / columns it is a stride-1 convolution of grad_out with 1, 2, 2 or 4 of the nine
+ * taps; grad_out is staged once per workgroup and feeds the four classes' accumulators tap by tap -- the matrix cores do
+ * exactly the forward's flops (no multiplications by inserted zeros), grad_out is read once:
  *   grad_in = (residual ? residual : 0) + conv_transpose2d(grad_out, weight, stride 2, pad 1) cropped to H x W
  *   wperm_t  cp_conv_mfma_prepare(weight [Cout][Cin][3][3], Cin := Cout, Cout := Cin, taps 9, transposed = 6)
+ *   grad_out [B][Cout][(H - 1) / 2 + 1][(W - 1) / 2 + 1] -> grad_in [B][Cin][H][W], every element written
  *   residual [B][Cin][H][W] or NULL (may be grad_in itself: every element is read, then written, by the same lane) */
 int cp_conv3x3_s2_input_grad(const float* grad_out, const void* wperm_t, const float* residual, float* grad_in, int32_t B,
                              int32_t Cin, int32_t H, int32_t W, int32_t Cout, void* stream);

@@ -213,10 +213,11 @@ def test_multi_source_needs_whole_k_steps():
 def test_training_trajectory_matches_exact_arithmetic():
     """Eight Adam steps of DLA-34 + DCNv2 on synthetic data, twice in fresh processes: default arithmetic (split-bf16
     convolutions and DCN backward) against library convolutions + exact-f32 DCN backward.  Step 0 (same weights):
-    every loss term agrees to 1e-4 relative.  Later steps are compared on the heat-map loss only, at 4 %: with
-    random-init weights Adam's first updates amplify last-bit differences of tiny gradients, and two runs of the SAME
-    arithmetic already differ by 0.1-1 % there (float-atomic summation order in the weight gradients; the polygon
-    terms swing by far more) -- measured run-to-run spread of hm_l: <= 0.9 %."""
+    every loss term agrees to 1e-4 relative.  Later steps are compared on the heat-map loss only: steps 1-2 (the
+    first updates: a wrong gradient shows here) at 1 % (measured 0.02 % / 0.15 %), steps 3-7 at 8 % -- with
+    random-init weights Adam amplifies last-bit differences of tiny gradients, and two runs of the SAME arithmetic
+    already differ by 1.5-2.5 % there (float-atomic summation order in the weight gradients; the polygon terms swing
+    by far more)."""
     import json, os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     runs = []
@@ -229,8 +230,8 @@ def test_training_trajectory_matches_exact_arithmetic():
     for k in runs[0][0]:
         a, b = runs[0][0][k], runs[1][0][k]
         assert abs(a - b) <= 1e-4 * max(abs(b), 1e-3), (k, a, b)
-    for a, b in zip(*runs):
-        assert abs(a["hm_l"] - b["hm_l"]) <= 4e-2 * b["hm_l"], (a["hm_l"], b["hm_l"])
+    for i, (a, b) in enumerate(zip(*runs)):
+        assert abs(a["hm_l"] - b["hm_l"]) <= (1e-2 if i < 3 else 8e-2) * b["hm_l"], (i, a["hm_l"], b["hm_l"])
     assert runs[0][-1]["hm_l"] < 0.6 * runs[0][0]["hm_l"]    # and it does learn
 
 
@@ -332,23 +333,17 @@ def test_stride_2_pointwise_forward(shape):
 
 
 @pytest.mark.parametrize("shape", [(2, 32, 64, 40, 72), (1, 64, 128, 17, 33), (1, 128, 256, 64, 128), (2, 256, 512, 32, 64),
-                                   (1, 27, 64, 12, 130), (4, 32, 64, 128, 256)],
-                         ids=["32->64", "odd map", "128->256", "256->512", "ragged channels", "level2 size / 4"])
+                                   (1, 27, 64, 12, 130), (4, 32, 64, 128, 256), (2, 16, 32, 96, 160)],
+                         ids=["32->64", "odd map", "128->256", "256->512", "ragged channels", "level2 size / 4", "level1 (16 <- 32)"])
 def test_stride_2_input_gradient(shape):
-    """cp_conv3x3_s2_input_grad_class / cp_conv3x3_s2_input_grad: the input gradient of a 3x3 / stride 2 / pad 1
-    convolution (per parity class, and all four in one launch) against torch.nn.grad.conv2d_input in float64; every element of grad_in written (NaN prefill)."""
+    """cp_conv3x3_s2_input_grad: the input gradient of a 3x3 / stride 2 / pad 1 convolution against
+    torch.nn.grad.conv2d_input in float64; every element of grad_in written (NaN prefill)."""
     B, ci, co, H, W = shape
     L = _C.lib()
     Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
     w, go = _t("s2gw%s" % (shape,), (co, ci, 3, 3), 0.05), _t("s2go%s" % (shape,), (B, co, Ho, Wo))
-    gx = torch.full((B, ci, H, W), float("nan"), device=DEV)
-    for cls in range(4):
-        wp = torch.empty(L.cp_conv_mfma_weight_bytes(co, ci, 9), dtype=torch.uint8, device=DEV)
-        _C.check(L.cp_conv_mfma_prepare(P(w), co, ci, 9, 2 + cls, P(wp), _C.stream()), "prepare")
-        _C.check(L.cp_conv3x3_s2_input_grad_class(P(go), P(wp), P(gx), B, ci, H, W, co, cls >> 1, cls & 1, _C.stream()), "igrad")
     ref = torch.nn.grad.conv2d_input((B, ci, H, W), w.double(), go.double(), stride=2, padding=1)
-    assert torch.isfinite(gx).all() and _rel(gx, ref) <= TOL
-    # the one-launch form (four class accumulators over one staged grad_out tile), alone and onto a residual in place
+    # one launch (four class accumulators over one staged grad_out tile), alone and onto a residual in place
     wp = torch.empty(L.cp_conv_mfma_weight_bytes(co, ci, 9), dtype=torch.uint8, device=DEV)
     _C.check(L.cp_conv_mfma_prepare(P(w), co, ci, 9, 6, P(wp), _C.stream()), "prepare")
     g1 = torch.full((B, ci, H, W), float("nan"), device=DEV)

@@ -8,14 +8,9 @@ for (B,ci,co,H,W) in [(4,32,64,512,1024),(4,64,128,256,512),(4,128,256,128,256),
     gx=torch.empty(B,ci,H,W,device="cuda")
     wp=torch.empty(L.cp_conv_mfma_weight_bytes(co,ci,9),dtype=torch.uint8,device="cuda")
     L.cp_conv_mfma_prepare(P(w),co,ci,9,6,P(wp),_C.stream())
-    wps=[]
-    for c in range(4):
-        q=torch.empty_like(wp); L.cp_conv_mfma_prepare(P(w),co,ci,9,2+c,P(q),_C.stream()); wps.append(q)
     def one(): L.cp_conv3x3_s2_input_grad(P(go),P(wp),None,P(gx),B,ci,H,W,co,_C.stream())
-    def four():
-        for c in range(4): L.cp_conv3x3_s2_input_grad_class(P(go),P(wps[c]),P(gx),B,ci,H,W,co,c>>1,c&1,_C.stream())
     def lib(): return torch.nn.grad.conv2d_input((B,ci,H,W),w,go,stride=2,padding=1)
-    for name,f in (("one",one),("four",four),("lib",lib)):
+    for name,f in (("one",one),("lib",lib)):
         for _ in range(3): f()
         torch.cuda.synchronize(); e0=torch.cuda.Event(enable_timing=True); e1=torch.cuda.Event(enable_timing=True)
         e0.record()
