@@ -85,6 +85,8 @@ _SIGNATURES = {
     "cp_conv_mfma_prepare": (c_int32, [_P, c_int32, c_int32, c_int32, c_int32, _P, _P]),
     "cp_conv_mfma_forward": (c_int32, [_P, _P, c_int32, _P, _P, _P, _P] + [c_int32] * 6 + [_P]),
     "cp_conv_mfma_forward_strided": (c_int32, [_P, _P, c_int32, _P, _P, _P, _P] + [c_int32] * 7 + [_P]),
+    "cp_conv_mfma_input_grad_relu_workspace_bytes": (c_size_t, [c_int32] * 4),
+    "cp_conv_mfma_input_grad_relu": (c_int32, [_P] * 5 + [c_int32] * 6 + [_P, c_size_t, _P]),
     "cp_conv3x3_s2_input_grad": (c_int32, [_P, _P, _P, _P] + [c_int32] * 5 + [_P]),
     "cp_conv3x3_mfma_wgrad_supported": (c_int32, [c_int32] * 4),
     "cp_conv3x3_mfma_wgrad": (c_int32, [_P, _P, _P] + [c_int32] * 5 + [_P]),

@@ -24,6 +24,8 @@
 //     others keep the matrix cores busy).
 #include "cp_common.h"
 
+#include <type_traits>
+
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -76,6 +78,18 @@ __global__ __launch_bounds__(256) void conv_mfma_wperm_kernel(const float* __res
   wp[e] = o;
 }
 
+// sum over the 16 lanes of a DPP row (lanes 16 g .. 16 g + 15), left in every lane of the row
+__device__ __forceinline__ float row16_sum(float v) {
+  auto dpp = [](float x, auto ctrl) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value, 0xF, 0xF, true));
+  };
+  v += dpp(v, std::integral_constant<int, 0xB1>{});           // quad_perm [1, 0, 3, 2]
+  v += dpp(v, std::integral_constant<int, 0x4E>{});           // quad_perm [2, 3, 0, 1]
+  v += dpp(v, std::integral_constant<int, 0x141>{});          // row_half_mirror
+  v += dpp(v, std::integral_constant<int, 0x140>{});          // row_mirror
+  return v;
+}
+
 constexpr int MAXSRC = 4;
 struct CvArgs {
   const float* xsrc[MAXSRC];   // the input is the channel concatenation of up to 4 tensors [B][csrc[i]][H][W]
@@ -85,6 +99,8 @@ struct CvArgs {
   const float* res;       // same shape as out, or null
   float* out;
   int Cin, H, W, Ho, Wo, Cout, nchunk, ncot, tiles_x, relu;   // H, W: input; Ho, Wo: output grid of the launch
+  const float* mask;           // same shape as out, or null: out = mask > 0 ? value : 0 (gradient through a ReLU whose output was `mask`)
+  float* colsum;               // null, or [B * tiles * 8][Cout] scratch: row (b, tile, wave, half) = sums of out per channel over RW x 16 pixels
   int Hf, Wf;                  // IG2: the gradient map (element (y, x) of class (py, px) goes to (2 y + py, 2 x + px)); else Ho, Wo
 };
 
@@ -337,22 +353,71 @@ __global__ __launch_bounds__(256 * KS, KS > 1 ? 4 : 2) void conv_mfma_kernel(CvA
     }
     return;
   }
+  // The accumulators hold (co = 4 g + r, px = c) and, in the tile to the right, (co, px = 16 + c): 64-byte runs per
+  // channel.  v_permlane16_swap trades the odd 16-lane rows of the left tile with the even rows of the right one, so
+  // that a row PAIR (g & ~1, g | 1) carries 32 consecutive pixels of one channel -- every store / residual / mask
+  // access of the epilogue is a whole 128-byte line (the 1x1 forms and the masked input gradient are bound by them).
+  // Branch-free: invalid elements get an offset past the descriptor's range (loads return 0, stores are dropped), so
+  // the residual / mask loads of a 16-channel fragment row are all in flight together (with a branch per element every
+  // load waited out its own latency: the masked input gradient of the heads ran 4x over its traffic).
+  const int x = x0 + c + 16 * (g & 1);
+  const int cot0 = cot * MT * 16;
+  const unsigned span = (unsigned)min(a.Cout - cot0, MT * 16) * (unsigned)HWf * 4u;       // this workgroup's channels
+  const long long tbase = (long long)b * a.Cout * HWf + (long long)cot0 * HWf;
+  const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc(a.out + tbase, 0, (int)span, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_r =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.res ? a.res + tbase : a.out), 0, a.res ? (int)span : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_m =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.mask ? a.mask + tbase : a.out), 0, a.mask ? (int)span : 0, 0x00020000);
+  constexpr unsigned EOOB = 0x80000000u;
 #pragma unroll
   for (int m = 0; m < MT; ++m) {
+    unsigned off[4][RW][2];
+    float val[4][RW][2], rv[4][RW][2], mv[4][RW][2];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int co = (cot * MT + m) * 16 + 4 * g + r;
-      if (co >= a.Cout) continue;
-      const float bv = a.bias ? a.bias[co] : 0.f;
+      const int col[2] = {m * 16 + r + 4 * (g & ~1), m * 16 + r + 4 * (g | 1)};      // channel within the workgroup's tile
 #pragma unroll
-      for (int n = 0; n < NT; ++n) {
-        const int y = y0 + wid * RW + (n >> 1), x = x0 + (n & 1) * 16 + c;
-        if (y < a.Ho && x < a.Wo) {
-          const long long o = (long long)co * HWf + (long long)y * a.Wf + x;
-          float v = acc[m][n][r] + bv;
-          if (rb) v += rb[o];
+      for (int rp = 0; rp < RW; ++rp) {
+        // (__builtin_bit_cast of a vector ELEMENT lvalue reads element 0 under hipcc 7.2: copy to scalars first)
+        const float e0 = acc[m][2 * rp][r], e1 = acc[m][2 * rp + 1][r];
+        const auto sw = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, e0), __builtin_bit_cast(unsigned, e1),
+                                                         false, false);
+        val[r][rp][0] = __builtin_bit_cast(float, (unsigned)sw[0]);
+        val[r][rp][1] = __builtin_bit_cast(float, (unsigned)sw[1]);
+        const int y = y0 + wid * RW + rp;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const bool ok = cot0 + col[j] < a.Cout && y < a.Ho && x < a.Wo;
+          off[r][rp][j] = ok ? ((unsigned)col[j] * (unsigned)HWf + (unsigned)(y * a.Wf + x)) * 4u : EOOB;
+          if (a.res) rv[r][rp][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_r, off[r][rp][j], 0, 0));
+          if (a.mask) mv[r][rp][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_m, off[r][rp][j], 0, 0));
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int co[2] = {cot0 + m * 16 + r + 4 * (g & ~1), cot0 + m * 16 + r + 4 * (g | 1)};
+      float csum[2] = {0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const float bv = (a.bias && co[j] < a.Cout) ? a.bias[co[j]] : 0.f;
+#pragma unroll
+        for (int rp = 0; rp < RW; ++rp) {
+          float v = val[r][rp][j] + bv;
+          if (a.res) v += rv[r][rp][j];
           if (a.relu) v = fmaxf(v, 0.f);
-          ob[o] = v;
+          if (a.mask && !(mv[r][rp][j] > 0.f)) v = 0.f;
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs_o, off[r][rp][j], 0, 0);
+          csum[j] += off[r][rp][j] == EOOB ? 0.f : v;
+        }
+      }
+      if (a.colsum) {                                          // (wave-uniform) this 16-lane row's RW x 16 pixels of co[0], co[1]
+        const long long row = ((((long long)b * (gridDim.x / a.ncot) + tile) * 4 + wid) * 2 + (g & 1)) * a.Cout;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const float t = row16_sum(csum[j]);
+          if (c == 0 && co[j] < a.Cout) a.colsum[row + co[j]] = t;
         }
       }
     }
@@ -369,6 +434,20 @@ __global__ __launch_bounds__(256 * KS, KS > 1 ? 4 : 2) void conv_mfma_kernel(CvA
     }
   }
 #endif
+}
+
+// out[c] += sum over rows of part[row][c] (the per-wave channel sums of a colsum launch): grid (ceil(C / 64), 32),
+// workgroup = 64 channels x 4 row phases; one float atomic per workgroup and channel (32 per address)
+__global__ __launch_bounds__(256) void colsum_reduce_kernel(const float* __restrict__ part, int nrows, int C,
+                                                            float* __restrict__ out) {
+  __shared__ float red[4][64];
+  const int cl = threadIdx.x & 63, ph = threadIdx.x >> 6, c = blockIdx.x * 64 + cl;
+  float s = 0.f;
+  if (c < C)
+    for (int r = blockIdx.y * 4 + ph; r < nrows; r += gridDim.y * 4) s += part[(long long)r * C + c];
+  red[ph][cl] = s;
+  __syncthreads();
+  if (ph == 0 && c < C) atomicAdd(&out[c], (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]));
 }
 
 int tiles16(int Cout) { return (Cout + 63) / 64 * 4; }             // 16-row weight tiles, padded to whole groups of 4
@@ -412,7 +491,7 @@ int cp_conv3x3_mfma_prepare(const float* weight, int32_t Cin, int32_t Cout, int3
 // builds with torch.cat before a 1x1 `Root` convolution, pose_dla_dcn.py:148-166) -- read in place, never
 // materialised.  With several sources every cs[i] must be a multiple of 32.  taps = 9: 3x3 / pad 1; taps = 1: 1x1.
 // Tile-variant choice and launch for a filled-in argument block (a.Ho x a.Wo: the launch's output grid).
-static int conv_dispatch(CvArgs& a, int B, int Cout, int taps, int stride, hipStream_t st) {
+static int conv_dispatch(CvArgs& a, int B, int Cout, int taps, int stride, hipStream_t st, int* tiles_out = nullptr) {
   const int Ho = a.Ho;
   // Tile variant by how many workgroups it yields (the chip wants >= 2 per CU): 64 output channels x 8 rows is the
   // most efficient (fewest fragment bytes per MFMA); layers that cannot fill the CUs with it take 32 channels
@@ -421,6 +500,7 @@ static int conv_dispatch(CvArgs& a, int B, int Cout, int taps, int stride, hipSt
   auto launch = [&](auto kernel, int mt, int th, int ks) {
     a.ncot = (Cout + 16 * mt - 1) / (16 * mt);
     const int tiles = a.tiles_x * ((Ho + th - 1) / th);
+    if (tiles_out) *tiles_out = tiles;
     hipLaunchKernelGGL(kernel, dim3(tiles * a.ncot, B), dim3(256 * ks), 0, st, a);
   };
   if (stride == 2 && taps == 1) {                    // 1x1 over every second pixel: the 1x1 forms on the output grid
@@ -448,9 +528,10 @@ static int conv_dispatch(CvArgs& a, int B, int Cout, int taps, int stride, hipSt
   return cp_launch_status();
 }
 
-int cp_conv_mfma_forward_strided(const float* const* xs, const int32_t* cs, int32_t nsrc, const void* wperm,
-                                 const float* bias, const float* residual, float* out, int32_t B, int32_t H, int32_t W,
-                                 int32_t Cout, int32_t taps, int32_t stride, int32_t relu, void* stream) {
+static int conv_forward_impl(const float* const* xs, const int32_t* cs, int32_t nsrc, const void* wperm, const float* bias,
+                             const float* residual, const float* mask, float* colsum, float* out, int32_t B, int32_t H,
+                             int32_t W, int32_t Cout, int32_t taps, int32_t stride, int32_t relu, void* stream,
+                             int* tiles_out = nullptr) {
   hipStream_t st = (hipStream_t)stream;
   CP_CHECK_ARG(xs && cs && wperm && out && B >= 1 && nsrc >= 1 && nsrc <= MAXSRC && (taps == 1 || taps == 9));
   if (stride != 1 && stride != 2) return CP_EUNSUPPORTED;
@@ -480,7 +561,47 @@ int cp_conv_mfma_forward_strided(const float* const* xs, const int32_t* cs, int3
   a.tiles_x = (a.Wo + TW - 1) / TW;
   a.relu = relu;
   a.Hf = a.Ho; a.Wf = a.Wo;
-  return conv_dispatch(a, B, Cout, taps, stride, st);
+  a.mask = mask; a.colsum = colsum;
+  if ((long long)a.Ho * a.Wo * 64 * 4 >= 0x7FFFFFF0ll) return CP_EUNSUPPORTED;     // (32-bit offsets within a channel tile)
+  return conv_dispatch(a, B, Cout, taps, stride, st, tiles_out);
+}
+
+int cp_conv_mfma_forward_strided(const float* const* xs, const int32_t* cs, int32_t nsrc, const void* wperm,
+                                 const float* bias, const float* residual, float* out, int32_t B, int32_t H, int32_t W,
+                                 int32_t Cout, int32_t taps, int32_t stride, int32_t relu, void* stream) {
+  return conv_forward_impl(xs, cs, nsrc, wperm, bias, residual, nullptr, nullptr, out, B, H, W, Cout, taps, stride, relu,
+                           stream);
+}
+
+// Input gradient of a stride-1 convolution (3x3 / pad 1 or 1x1) whose INPUT was the output `y` of a bias + ReLU
+// epilogue (the heads' Conv2d(3x3, bias) -> ReLU -> Conv2d(1x1), pose_dla_dcn.py:445-462), with that ReLU's backward
+// and its bias gradient in the epilogue:
+//   grad_y[b][c][p] = [y[b][c][p] > 0] * sum_{co, taps} w[co][c][tap'] * grad_out[b][co][p + tap]
+//   grad_bias[c]   += sum_{b, p} grad_y[b][c][p]
+// instead of writing the unmasked gradient, re-reading it with y and writing it again in a separate pass.  The bias
+// gradient: every 16-lane row leaves its pixels' channel sums in the workspace (plain stores), a second small kernel adds the
+// rows up (an atomic per wave and channel straight into grad_bias ran 5x longer than the convolution: 8 192 same-address
+// adds per channel at the training size).
+// wperm_t: cp_conv_mfma_prepare(w, Cin := Cout of the convolution, Cout := its Cin, taps, transposed = 1).
+size_t cp_conv_mfma_input_grad_relu_workspace_bytes(int32_t B, int32_t Cin, int32_t H, int32_t W) {
+  if (B < 1 || Cin < 1 || H < 1 || W < 1) return 0;
+  return (size_t)B * ((W + TW - 1) / TW) * ((H + 3) / 4) * 8 * Cin * sizeof(float);     // (the narrowest tile form)
+}
+
+int cp_conv_mfma_input_grad_relu(const float* grad_out, const void* wperm_t, const float* y, float* grad_y,
+                                 float* grad_bias, int32_t B, int32_t Cin, int32_t H, int32_t W, int32_t Cout,
+                                 int32_t taps, void* workspace, size_t workspace_bytes, void* stream) {
+  CP_CHECK_ARG(grad_out && y && grad_y && (!grad_bias || workspace));
+  if (grad_bias && workspace_bytes < cp_conv_mfma_input_grad_relu_workspace_bytes(B, Cin, H, W)) return CP_EWORKSPACE;
+  const float* xs[1] = {grad_out};
+  const int32_t cs[1] = {Cout};
+  int tiles = 0;
+  const int rc = conv_forward_impl(xs, cs, 1, wperm_t, nullptr, nullptr, y, grad_bias ? (float*)workspace : nullptr, grad_y,
+                                   B, H, W, Cin, taps, 1, 0, stream, &tiles);
+  if (rc != CP_OK || !grad_bias) return rc;
+  hipLaunchKernelGGL(colsum_reduce_kernel, dim3((Cin + 63) / 64, 32), dim3(256), 0, (hipStream_t)stream,
+                     (const float*)workspace, B * tiles * 8, Cin, grad_bias);
+  return cp_launch_status();
 }
 
 // INPUT GRADIENT of a 3x3 / stride 2 / pad 1 convolution (the first convolution of DLA levels 2-5, pose_dla_dcn.py:32-40;
@@ -511,6 +632,7 @@ int cp_conv3x3_s2_input_grad(const float* grad_out, const void* wperm_t, const f
   a.tiles_x = (Wo + TW - 1) / TW;
   a.relu = 0;
   a.Hf = H; a.Wf = W;
+  a.mask = nullptr; a.colsum = nullptr;
   auto wgs = [&](int mt, int th) { return (long long)a.tiles_x * ((Ho + th - 1) / th) * B * ((Cin + 16 * mt - 1) / (16 * mt)); };
   auto launch = [&](auto kernel, int mt, int th) {
     a.ncot = (Cin + 16 * mt - 1) / (16 * mt);

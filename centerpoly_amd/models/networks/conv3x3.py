@@ -261,6 +261,61 @@ def conv_bias_act(conv, x, relu):
     return _ConvBiasActFn.apply(x.contiguous(), conv.weight, conv.bias, bool(relu))
 
 
+class _HeadFn(torch.autograd.Function):
+    """A detection head in training -- Conv2d(3x3, bias) -> ReLU -> Conv2d(1x1, bias)
+    (src/lib/models/networks/pose_dla_dcn.py:445-462) -- as ONE autograd node: both forwards with their epilogues in
+    the kernels; backward: the 1x1 convolution's input gradient leaves the kernel already masked by the ReLU with the
+    3x3 bias gradient summed in its epilogue (cp_conv_mfma_input_grad_relu) -- no separate pass over the
+    [B][head_conv][H][W] map (4 x 537 MB at the training size)."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2):
+        c1, cin, c2 = w1.shape[0], w1.shape[1], w2.shape[0]
+        y = _launch(x, _prepare(w1, cin, c1, False), b1, None, c1, True, 9)
+        out = _launch(y, _prepare(w2, c1, c2, False), b2, None, c2, False, 1)
+        ctx.save_for_backward(x, w1, w2, y)
+        return out
+
+    @staticmethod
+    def backward(ctx, go):
+        x, w1, w2, y = ctx.saved_tensors
+        go = go.contiguous()
+        B, c2, H, W = go.shape
+        c1 = w1.shape[0]
+        L = _C.lib()
+        gb2 = _C.zeros((c2,), go.device)
+        _C.check(L.cp_channel_sum_accumulate(_C.ptr(go), _C.ptr(gb2), B, c2, H * W, _C.stream()), "cp_channel_sum_accumulate")
+        _, gw2 = grads(y, w2, go, False, ctx.needs_input_grad[3])
+        g = torch.empty_like(y)
+        gb1 = _C.zeros((c1,), go.device)
+        end = _C.kernel_timer.start(("conv1x1_igrad_relu", c2, c1, H, W, B)) if _C.kernel_timer is not None else None
+        ws = _C.workspace(L.cp_conv_mfma_input_grad_relu_workspace_bytes(B, c1, H, W), go.device)
+        _C.check(L.cp_conv_mfma_input_grad_relu(_C.ptr(go), _C.ptr(_prepare(w2, c2, c1, True)), _C.ptr(y), _C.ptr(g),
+                                                _C.ptr(gb1), B, c1, H, W, c2, 1, _C.ptr(ws), ws.numel(), _C.stream()),
+                 "cp_conv_mfma_input_grad_relu")
+        if end is not None:
+            end.record()
+        gx, gw1 = grads(x, w1, g, ctx.needs_input_grad[0], ctx.needs_input_grad[1], min_k=MIN_CIN)
+        return gx, gw1, gb1, gw2, gb2
+
+
+def head_train(fc, x):
+    """fc(x) for a head Sequential(Conv2d(3x3, bias), ReLU, Conv2d(1x1, bias)) in training as one autograd node
+    (_HeadFn); None when a shape is not the MFMA kernel's (the caller composes the head from its pieces)."""
+    c0, c2 = fc[0], fc[2]
+    if not (c0.bias is not None and c2.bias is not None and c0.kernel_size == (3, 3) and c2.kernel_size == (1, 1)
+            and c0.stride == (1, 1) and c2.stride == (1, 1) and usable(c0, x)):
+        return None
+    B, _, H, W = x.shape
+    L = _C.lib()
+    c1, co = c0.out_channels, c2.out_channels
+    if not (c2.padding == (0, 0) and c2.dilation == (1, 1) and c2.groups == 1 and c1 >= MIN_CIN
+            and L.cp_conv3x3_mfma_supported(c1, co, H, W) and L.cp_conv3x3_mfma_supported(co, c1, H, W)
+            and _fills(B, c1, co, H, W) and (H * W) % 4 == 0 and B * max(c1, co) <= 65535):
+        return None
+    return _HeadFn.apply(x.contiguous(), c0.weight, c0.bias, c2.weight, c2.bias)
+
+
 def conv_raw(conv, x):
     """conv(x) WITHOUT its bias, differentiable: the MFMA kernel for its shapes, the library otherwise."""
     if usable(conv, x):

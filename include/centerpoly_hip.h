@@ -250,6 +250,19 @@ int cp_conv_mfma_forward(const float* const* xs, const int32_t* cs, int32_t nsrc
 int cp_conv_mfma_forward_strided(const float* const* xs, const int32_t* cs, int32_t nsrc, const void* wperm,
                                  const float* bias, const float* residual, float* out, int32_t B, int32_t H, int32_t W,
                                  int32_t Cout, int32_t taps, int32_t stride, int32_t relu, void* stream);
+/* Input gradient of a stride-1 convolution (3x3 / pad 1 or 1x1) whose INPUT was the output y of a bias + ReLU epilogue
+ * (the heads' Conv2d(3x3, bias) -> ReLU -> Conv2d(1x1), src/lib/models/networks/pose_dla_dcn.py:445-462), with that
+ * ReLU's backward and its bias gradient in the kernel's epilogue (threshold_backward + the bias sum in the reference):
+ *   grad_y[b][c][p] = [y[b][c][p] > 0] * sum_{co, tap} weight[co][c][tap'] * grad_out[b][co][p + tap]
+ *   grad_bias[c]   += sum_{b, p} grad_y[b][c][p]     (NULL: not wanted; accumulated into: zero it first.  Every wave
+ *                     leaves its channel sums in the workspace, a second small kernel adds them up)
+ *   wperm_t  cp_conv_mfma_prepare(weight [Cout][Cin][k][k], Cin := Cout, Cout := Cin, taps, transposed = 1)
+ *   grad_out [B][Cout][H][W], y and grad_y [B][Cin][H][W].  Cout below 32 multiplies zeros up to 32 (the launch is
+ *   bound by the two [B][Cin][H][W] streams). */
+size_t cp_conv_mfma_input_grad_relu_workspace_bytes(int32_t B, int32_t Cin, int32_t H, int32_t W);
+int cp_conv_mfma_input_grad_relu(const float* grad_out, const void* wperm_t, const float* y, float* grad_y,
+                                 float* grad_bias, int32_t B, int32_t Cin, int32_t H, int32_t W, int32_t Cout,
+                                 int32_t taps, void* workspace, size_t workspace_bytes, void* stream);
 /* Input gradient of a 3x3 / stride 2 / pad 1 convolution (the first convolution of DLA levels 1-5,
  * src/lib/models/networks/pose_dla_dcn.py:32-40,236-246; cuDNN's backward-data in the reference) in ONE launch: per parity
  * class (py, px) of the gradient's rows / columns it is a stride-1 convolution of grad_out with 1, 2, 2 or 4 of the nine

@@ -355,6 +355,38 @@ def test_stride_2_input_gradient(shape):
     assert _rel(g2, ref + res.double()) <= TOL
 
 
+@pytest.mark.parametrize("cfg", [(2, 64, 256, 8, 40, 72), (1, 64, 128, 32, 64, 128), (2, 48, 64, 1, 17, 36), (4, 64, 256, 2, 32, 64)],
+                         ids=["hm (8)", "poly (32)", "pseudo_depth (1), ragged map", "reg (2)"])
+def test_training_head_single_node(cfg):
+    """conv3x3.head_train: Conv2d(3x3, bias) -> ReLU -> Conv2d(1x1, bias) as one autograd node whose backward masks the
+    1x1 input gradient and sums the 3x3 bias gradient in the kernel's epilogue (cp_conv_mfma_input_grad_relu): outputs and
+    all five gradients against float64 torch."""
+    from centerpoly_amd.models.networks import conv3x3
+    B, cin, hc, co, H, W = cfg
+    fc = torch.nn.Sequential(torch.nn.Conv2d(cin, hc, 3, padding=1), torch.nn.ReLU(), torch.nn.Conv2d(hc, co, 1)).to(DEV)
+    with torch.no_grad():
+        fc[0].weight.copy_(_t("hw1%s" % (cfg,), (hc, cin, 3, 3), 0.05)); fc[0].bias.copy_(_t("hb1%s" % (cfg,), (hc,), 0.3))
+        fc[2].weight.copy_(_t("hw2%s" % (cfg,), (co, hc, 1, 1), 0.1)); fc[2].bias.copy_(_t("hb2%s" % (cfg,), (co,)))
+    x = _t("hx%s" % (cfg,), (B, cin, H, W)).requires_grad_(True)
+    out = conv3x3.head_train(fc, x)
+    if out is None:
+        pytest.skip("shape not taken by the MFMA kernels (grid too small)")
+    go = _t("hgo%s" % (cfg,), tuple(out.shape))
+    params = [fc[0].weight, fc[0].bias, fc[2].weight, fc[2].bias]
+    grads = torch.autograd.grad(out, [x] + params, go)
+    xd = x.detach().double().requires_grad_(True)
+    pd = [p.detach().double().requires_grad_(True) for p in params]
+    # the reference takes the ReLU's mask from the kernel's own hidden map (the same launch head_train makes): a hidden
+    # value within rounding of zero may sit on the other side in float64, and one flipped element is 1e-2 of grad_x's norm
+    with torch.no_grad():
+        keep = (conv3x3.conv_bias_act(fc[0], x.detach(), True) > 0).double()
+    yd = F.conv2d(F.conv2d(xd, pd[0], pd[1], padding=1) * keep, pd[2], pd[3])
+    gd = torch.autograd.grad(yd, [xd] + pd, go.double())
+    assert _rel(out, yd.detach()) <= TOL
+    for name, a, b in zip(("x", "w1", "b1", "w2", "b2"), grads, gd):
+        assert torch.isfinite(a).all() and _rel(a, b) <= 1e-4, name
+
+
 def test_stride_2_autograd_wrapper():
     """conv_raw on a stride-2 3x3 convolution: forward and input gradient from the MFMA kernel, weight gradient from
     the library."""
