@@ -186,6 +186,109 @@ class _Conv3x3Fn(torch.autograd.Function):
         return grads(x, weight, go, ctx.needs_input_grad[0], ctx.needs_input_grad[1], min_k=MIN_CIN) + (None,)
 
 
+class _Conv3x3SkipFn(torch.autograd.Function):
+    """conv(x) together with x itself as a second output, for a block whose skip connection starts at the convolution's
+    input (BasicBlock, src/lib/models/networks/pose_dla_dcn.py:32-60: `out += residual` with residual = x): the gradient
+    arriving over the skip is added in the input-gradient kernel's epilogue (its `residual` operand) instead of by
+    autograd's separate accumulation pass over the map."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        ctx.save_for_backward(x, weight)
+        cout, cin = weight.shape[0], weight.shape[1]
+        y = _launch(x, _prepare(weight, cin, cout, False), None, None, cout, False, weight.shape[2] * weight.shape[3])
+        return y, x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, go, gskip):
+        x, weight = ctx.saved_tensors
+        cout, cin = weight.shape[0], weight.shape[1]
+        B, _, H, W = x.shape
+        if go is None:                                  # (only the skip was used)
+            return gskip, None
+        go = go.contiguous()
+        gx = None
+        if ctx.needs_input_grad[0] and gskip is not None and gskip.is_contiguous() \
+                and _C.lib().cp_conv3x3_mfma_supported(cout, cin, H, W):
+            gx = _launch(go, _prepare(weight, cout, cin, True), None, gskip, cin, False, weight.shape[2] * weight.shape[3])
+            _, gw = grads(x, weight, go, False, ctx.needs_input_grad[1], min_k=MIN_CIN)
+            return gx, gw
+        gx, gw = grads(x, weight, go, ctx.needs_input_grad[0], ctx.needs_input_grad[1], min_k=MIN_CIN)
+        if gx is not None and gskip is not None:
+            gx = gx + gskip
+        return gx, gw
+
+
+def conv_raw_skip(conv, x):
+    """(conv(x) without bias, x) for a block whose skip connection is the convolution's own input: one autograd node
+    that adds the skip's gradient inside the input-gradient launch (_Conv3x3SkipFn); None when the shape is not the
+    MFMA kernel's or the stride is not 1."""
+    if conv.bias is not None or conv.stride != (1, 1) or conv.kernel_size != (3, 3) or not usable(conv, x) \
+            or conv.in_channels < MIN_CIN \
+            or conv.out_channels < MIN_CIN or not torch.is_grad_enabled() or not x.requires_grad:
+        return None
+    return _Conv3x3SkipFn.apply(x.contiguous(), conv.weight)
+
+
+class _ConcatConv1x1Fn(torch.autograd.Function):
+    """Training: the 1x1 convolution of a channel concatenation (`Root`, src/lib/models/networks/pose_dla_dcn.py:148-166:
+    conv(torch.cat(xs, 1))) without the concatenated copy: the forward reads the sources in place (as inference does),
+    the backward runs one input-gradient launch per source over its slice of the weight -- each gradient leaves
+    contiguous, where slices of the concatenation's gradient had to be copied before the next kernel could take them --
+    and one weight-gradient launch per source into its slice."""
+
+    @staticmethod
+    def forward(ctx, weight, *xs):
+        ctx.save_for_backward(weight, *xs)
+        cout, cin = weight.shape[0], weight.shape[1]
+        x0 = xs[0]
+        B, _, H, W = x0.shape
+        out = torch.empty((B, cout, H, W), dtype=torch.float32, device=x0.device)
+        end = _C.kernel_timer.start(("conv1x1_fwd", cin, cout, H, W, B)) if _C.kernel_timer is not None else None
+        n = len(xs)
+        ptrs, chans = (_C.c_void_p * n)(*[x.data_ptr() for x in xs]), (_C.c_int32 * n)(*[x.shape[1] for x in xs])
+        _C.check(_C.lib().cp_conv_mfma_forward(ptrs, chans, n, _C.ptr(_prepare(weight, cin, cout, False)), None, None,
+                                               _C.ptr(out), B, H, W, cout, 1, 0, _C.stream()), "cp_conv_mfma_forward")
+        if end is not None:
+            end.record()
+        return out
+
+    @staticmethod
+    def backward(ctx, go):
+        weight, xs = ctx.saved_tensors[0], ctx.saved_tensors[1:]
+        go = go.contiguous()
+        gxs, gws, c0 = [], [], 0
+        for i, x in enumerate(xs):
+            c = x.shape[1]
+            w_i = weight[:, c0:c0 + c].contiguous()
+            gx, gw = grads(x, w_i, go, ctx.needs_input_grad[1 + i], ctx.needs_input_grad[0], min_k=MIN_CIN)
+            gxs.append(gx)
+            gws.append(gw)
+            c0 += c
+        gw = torch.cat(gws, 1) if ctx.needs_input_grad[0] else None
+        return (gw,) + tuple(gxs)
+
+
+def concat_conv1x1(conv, xs):
+    """conv(torch.cat(xs, 1)) for a bias-free 1x1 convolution in training, the sources read in place
+    (_ConcatConv1x1Fn); None when the shapes are not the MFMA kernel's."""
+    if not (_ENABLED and conv.bias is None and conv.kernel_size == (1, 1) and conv.stride == (1, 1)
+            and conv.padding == (0, 0) and conv.groups == 1 and 2 <= len(xs) <= 4 and torch.is_grad_enabled()):
+        return None
+    x0 = xs[0]
+    if not all(x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[0] == x0.shape[0]
+               and x.shape[2:] == x0.shape[2:] and x.shape[1] % 32 == 0 for x in xs):
+        return None
+    B, _, H, W = x0.shape
+    cin, cout = sum(x.shape[1] for x in xs), conv.out_channels
+    L = _C.lib()
+    if cin != conv.in_channels or cout < MIN_CIN or not _fills(B, cin, cout, H, W) \
+            or not all(L.cp_conv3x3_mfma_supported(x.shape[1], cout, H, W) and L.cp_conv3x3_mfma_supported(cout, x.shape[1], H, W)
+                       for x in xs):
+        return None
+    return _ConcatConv1x1Fn.apply(conv.weight, *[x.contiguous() for x in xs])
+
+
 def mfma_enabled():
     return _ENABLED
 

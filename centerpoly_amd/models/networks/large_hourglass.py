@@ -15,7 +15,7 @@ import torch.nn.functional as F
 
 from ... import _C
 from .conv3x3 import conv3x3_infer
-from .pose_dla_dcn import _conv_folded, _fold_conv_bn, _use_folded, bn_act, conv_train, heads_fused_infer
+from .pose_dla_dcn import _conv_folded, _fold_conv_bn, _use_folded, bn_act, conv_train, flush_batch_counts, heads_fused_infer
 
 # Inference (`prepare_inference()`): every BatchNorm is folded into its convolution (weights scaled,
 # shift as a bias) and each conv is followed by ONE fused in-place pass -- + bias (+ residual) (+ ReLU),
@@ -265,6 +265,7 @@ class exkp(nn.Module):
                 else:
                     inter = self.relu(self.inters_[s](inter) + self.cnvs_[s](cnv))
                 inter = self.inters[s](inter)
+        flush_batch_counts()
         return outs
 
 

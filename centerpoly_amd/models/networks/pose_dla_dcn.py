@@ -286,14 +286,27 @@ class _BnAct(torch.autograd.Function):
         return gx, gw, gb, gres, None, None, None, None, None
 
 
+# BatchNorm2d.num_batches_tracked of the modules that took the fused path: incremented together by ONE multi-tensor
+# launch at the end of the network's forward (flush_batch_counts) instead of ~55 four-microsecond kernels per step.
+_PENDING_BATCH_COUNTS = []
+
+
+def flush_batch_counts():
+    if _PENDING_BATCH_COUNTS:
+        with torch.no_grad():
+            torch._foreach_add_(list(_PENDING_BATCH_COUNTS), 1)
+        del _PENDING_BATCH_COUNTS[:]
+
+
 def bn_act(bn, x, relu=True, residual=None):
     """relu(bn(x) + residual).  Training on a HIP device: one fused statistics pass + one fused
     apply pass (and two passes backward) instead of BatchNorm, add and ReLU kernels; otherwise
     the plain torch modules (eval mode normally takes the folded path before getting here)."""
     if bn.training and x.is_cuda and x.dtype == torch.float32 and bn.track_running_stats \
             and bn.affine and bn.momentum is not None and x.numel() // x.shape[1] > 1:
-        with torch.no_grad():
-            bn.num_batches_tracked += 1
+        _PENDING_BATCH_COUNTS.append(bn.num_batches_tracked)
+        if len(_PENDING_BATCH_COUNTS) >= 256:
+            flush_batch_counts()
         return _BnAct.apply(x, bn.weight, bn.bias, residual, bn.running_mean, bn.running_var,
                             float(bn.momentum), float(bn.eps), relu)
     y = bn(x)
@@ -320,7 +333,11 @@ class BasicBlock(nn.Module):
         if _use_folded(self):
             y = _conv_folded(x, self.conv1, self._folded[0], relu=True)
             return _conv_folded(y, self.conv2, self._folded[1], relu=True, residual=skip)
-        y = bn_act(self.bn1, conv_train(self.conv1, x), relu=True)
+        pair = conv3x3.conv_raw_skip(self.conv1, x) if (residual is None and x.is_cuda and self.training) else None
+        if pair is not None:                        # the skip starts at conv1's input: its gradient joins in conv1's kernel
+            y, skip = bn_act(self.bn1, pair[0], relu=True), pair[1]
+        else:
+            y = bn_act(self.bn1, conv_train(self.conv1, x), relu=True)
         return bn_act(self.bn2, conv_train(self.conv2, y), relu=True, residual=skip)
 
 
@@ -343,8 +360,10 @@ class Root(nn.Module):
                 if y is not None:
                     return y
             return _conv_folded(torch.cat(xs, 1), self.conv, self._folded, relu=True, residual=res)
-        return bn_act(self.bn, conv_train(self.conv, torch.cat(xs, 1)), relu=True,
-                      residual=xs[0] if self.residual else None)
+        y = conv3x3.concat_conv1x1(self.conv, xs) if (self.training and xs[0].is_cuda) else None
+        if y is None:
+            y = conv_train(self.conv, torch.cat(xs, 1))
+        return bn_act(self.bn, y, relu=True, residual=xs[0] if self.residual else None)
 
 
 class Tree(nn.Module):
@@ -769,6 +788,7 @@ class DLASeg(nn.Module):
         #  entries and never writes into its inputs, so the copies are not needed)
         y = [x[i] for i in range(self.last_level - self.first_level)]
         self.ida_up(y, 0, len(y))
+        flush_batch_counts()
         if getattr(self, "_heads_cat", None) is not None and not self.training \
                 and not torch.is_grad_enabled() and y[-1].is_cuda \
                 and (y[-1].shape[2] * y[-1].shape[3]) % 4 == 0:

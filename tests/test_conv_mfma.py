@@ -387,6 +387,46 @@ def test_training_head_single_node(cfg):
         assert torch.isfinite(a).all() and _rel(a, b) <= 1e-4, name
 
 
+def test_skip_gradient_joins_in_the_input_gradient_launch():
+    """conv3x3.conv_raw_skip: (conv(x), x) as one autograd node whose backward adds the skip's gradient in the
+    input-gradient kernel's epilogue; against float64 torch, with and without a gradient on the skip."""
+    from centerpoly_amd.models.networks import conv3x3
+    conv = torch.nn.Conv2d(64, 64, 3, padding=1, bias=False).to(DEV)
+    x = _t("skx", (2, 64, 64, 136)).requires_grad_(True)
+    y, skip = conv3x3.conv_raw_skip(conv, x)
+    assert skip.data_ptr() == x.data_ptr()
+    gy, gs = _t("skgy", tuple(y.shape)), _t("skgs", tuple(x.shape))
+    gx, gw = torch.autograd.grad([y, skip], (x, conv.weight), [gy, gs], retain_graph=True)
+    xd, wd = x.detach().double().requires_grad_(True), conv.weight.detach().double().requires_grad_(True)
+    yd = F.conv2d(xd, wd, padding=1)
+    gxd, gwd = torch.autograd.grad([yd, xd * 1.0], (xd, wd), [gy.double(), gs.double()])
+    assert _rel(y, yd.detach()) <= TOL and _rel(gx, gxd) <= 1e-4 and _rel(gw, gwd) <= 1e-4
+    (gx2,) = torch.autograd.grad(y, x, gy)                     # skip unused: plain input gradient
+    (gxd2,) = torch.autograd.grad(F.conv2d(xd, wd, padding=1), xd, gy.double())
+    assert _rel(gx2, gxd2) <= 1e-4
+
+
+@pytest.mark.parametrize("cs", [(64, 64), (128, 128, 64), (256, 256, 128, 64)], ids=["2 sources", "3 sources", "4 sources"])
+def test_concatenated_1x1_training_node(cs):
+    """conv3x3.concat_conv1x1 (Root in training): conv(cat(xs)) with the sources read in place, per-source input and
+    weight gradients; against float64 torch over the concatenation."""
+    from centerpoly_amd.models.networks import conv3x3
+    co = cs[0]
+    conv = torch.nn.Conv2d(sum(cs), co, 1, bias=False).to(DEV)
+    xs = [_t("ccx%d%s" % (i, cs), (2, c, 64, 128)).requires_grad_(True) for i, c in enumerate(cs)]
+    y = conv3x3.concat_conv1x1(conv, xs)
+    assert y is not None
+    go = _t("ccgo%s" % (cs,), tuple(y.shape))
+    grads = torch.autograd.grad(y, xs + [conv.weight], go)
+    xd = [x.detach().double().requires_grad_(True) for x in xs]
+    wd = conv.weight.detach().double().requires_grad_(True)
+    yd = F.conv2d(torch.cat(xd, 1), wd)
+    gd = torch.autograd.grad(yd, xd + [wd], go.double())
+    assert _rel(y, yd.detach()) <= TOL
+    for a, b in zip(grads, gd):
+        assert a.is_contiguous() and _rel(a, b) <= 1e-4
+
+
 def test_stride_2_autograd_wrapper():
     """conv_raw on a stride-2 3x3 convolution: forward and input gradient from the MFMA kernel, weight gradient from
     the library."""

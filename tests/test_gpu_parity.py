@@ -871,6 +871,8 @@ def test_fused_bn_act_vs_torch(shape, relu, with_res):
     np.testing.assert_allclose(yd.detach().cpu().numpy(), yc.detach().numpy(), rtol=1e-4, atol=1e-5)
     np.testing.assert_allclose(bd.running_mean.cpu().numpy(), bc.running_mean.numpy(), rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(bd.running_var.cpu().numpy(), bc.running_var.numpy(), rtol=1e-5, atol=1e-6)
+    from centerpoly_amd.models.networks.pose_dla_dcn import flush_batch_counts
+    flush_batch_counts()                      # (the networks' forward does this once for all their BatchNorms)
     assert int(bd.num_batches_tracked) == int(bc.num_batches_tracked) == 1
     gs = xc.grad.abs().max().item()
     np.testing.assert_allclose(xd.grad.cpu().numpy(), xc.grad.numpy(), rtol=1e-3, atol=1e-5 * max(gs, 1.0))
