@@ -311,6 +311,92 @@ __global__ __launch_bounds__(256) void dw_up_bwd_weight_kernel(const float* __re
   }
 }
 
+// f = 2 (every IDAUp / DLAUp level but one), both gradients in ONE pass over grad_out: a thread owns two adjacent input
+// pixels (columns 2t, 2t + 1) of R consecutive input rows; per row it needs grad_out rows 2i - 1 .. 2i + 2, columns
+// 4t - 1 .. 4t + 4 -- one aligned float4 and two dwords each, two of the four rows carried over from the previous input
+// row in registers -- and computes
+//   grad_x[i][2t + p]   = sum_{ky, kx} go[2i - 1 + ky][2(2t + p) - 1 + kx] * w[ky][kx]
+//   grad_w[ky][kx]     += x[i][2t + p] * go[2i - 1 + ky][2(2t + p) - 1 + kx]         (16 running sums per thread)
+// grad_out is read once for both (the separate kernels read it twice, one of them with a 16-way scattered pattern);
+// the workgroup's 256 x 16 partial weight sums meet in LDS and leave as 16 float atomics.
+constexpr int UB_R = 4;                                // input rows per thread
+__global__ __launch_bounds__(256) void dw_up2_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                         const float* __restrict__ go, float* __restrict__ gx,
+                                                         float* __restrict__ gw, int C, int H, int W) {
+  __shared__ float red[16][257];
+  const int bc = blockIdx.z, c = bc % C;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int t = blockIdx.x * 64 + tx;                  // pixel pair of the row
+  const int i0 = (blockIdx.y * 4 + ty) * UB_R;
+  const int Ho = 2 * H, Wo = 2 * W;
+  const bool live = 2 * t < W && i0 < H;
+  float wk[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) wk[a][b] = w[(long long)c * 16 + a * 4 + b];
+  float acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = 0.f;
+  const __amdgpu_buffer_rsrc_t rs_g = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(go + (long long)bc * Ho * Wo), 0, (int)((unsigned)Ho * (unsigned)Wo * 4u), 0x00020000);
+  constexpr unsigned OOBU = 0x80000000u;
+  auto load_row = [&](int oy, float (&g)[6]) {         // columns 4t - 1 .. 4t + 4 of grad_out row oy (zero outside)
+    const bool rok = live && oy >= 0 && oy < Ho;
+    const unsigned base = rok ? ((unsigned)oy * (unsigned)Wo + 4u * (unsigned)t) * 4u : OOBU;
+    const f32x4 m = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_g, base, 0, 0));
+    g[0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_g, (rok && t > 0) ? base - 4u : OOBU, 0, 0));
+    g[1] = m[0]; g[2] = m[1]; g[3] = m[2]; g[4] = m[3];
+    g[5] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_g, (rok && 4 * t + 4 < Wo) ? base + 16u : OOBU, 0, 0));
+  };
+  float g[4][6];                                       // grad_out rows 2i - 1 .. 2i + 2 of the current input row
+  load_row(2 * i0 - 1, g[0]);
+  load_row(2 * i0, g[1]);
+  const float* xc = x + (long long)bc * H * W;
+  float* gc = gx ? gx + (long long)bc * H * W : nullptr;
+#pragma unroll
+  for (int k = 0; k < UB_R; ++k) {
+    const int i = i0 + k;
+    load_row(2 * i + 1, g[2]);
+    load_row(2 * i + 2, g[3]);
+    const bool ok = live && i < H;
+    f32x2 xv = f32x2{0.f, 0.f};
+    if (ok) xv = *reinterpret_cast<const f32x2*>(xc + (long long)i * W + 2 * t);
+    float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+    for (int ky = 0; ky < 4; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < 4; ++kx) {
+        s0 += g[ky][kx] * wk[ky][kx];                  // pixel 2t: window columns kx
+        s1 += g[ky][kx + 2] * wk[ky][kx];              // pixel 2t + 1: window columns kx + 2
+        acc[ky][kx] += xv[0] * g[ky][kx] + xv[1] * g[ky][kx + 2];
+      }
+    if (ok && gc) *reinterpret_cast<f32x2*>(gc + (long long)i * W + 2 * t) = f32x2{s0, s1};
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {                      // the next input row starts two grad_out rows further down
+      g[0][q] = g[2][q];
+      g[1][q] = g[3][q];
+    }
+  }
+  if (!gw) return;                                     // (workgroup-uniform)
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) red[a * 4 + b][threadIdx.x] = acc[a][b];
+  __syncthreads();
+  const int tap = threadIdx.x >> 4, seg = threadIdx.x & 15;
+  float sum = 0.f;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) sum += red[tap][seg * 16 + q];
+  sum += __shfl_xor(sum, 1);
+  sum += __shfl_xor(sum, 2);
+  sum += __shfl_xor(sum, 4);
+  sum += __shfl_xor(sum, 8);
+  if (seg == 0 && sum != 0.f) atomicAdd(&gw[(long long)c * 16 + tap], sum);
+}
+
 }  // namespace
 
 extern "C" int cp_depthwise_up_backward(const float* x, const float* weight, const float* grad_out,
@@ -320,6 +406,14 @@ extern "C" int cp_depthwise_up_backward(const float* x, const float* weight, con
   if (f != 2 && f != 4) return CP_EUNSUPPORTED;          // 2f x 2f taps must fit 256 threads
   if ((long long)B * C > 65535 || H > 65535 || B > 65535 || C > 65535) return CP_EUNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
+  if (f == 2 && (W & 1) == 0 && (grad_weight ? x != nullptr : true) && (long long)H * W * 16 < 0x7FFFFFF0ll &&
+      (H + 4 * UB_R - 1) / (4 * UB_R) <= 65535) {
+    // one pass over grad_out for both gradients (x may be NULL when only grad_x is wanted: it is then not read)
+    const dim3 grid((W / 2 + 63) / 64, (H + 4 * UB_R - 1) / (4 * UB_R), B * C);
+    hipLaunchKernelGGL(dw_up2_bwd_kernel, grid, dim3(256), 0, st, grad_weight ? x : grad_out, weight, grad_out, grad_x,
+                       grad_weight, C, H, W);
+    return cp_launch_status();
+  }
   if (grad_x) {
     dim3 grid((W + 255) / 256, H, B * C);
     if (f == 2) hipLaunchKernelGGL(dw_up_bwd_data_kernel<2>, grid, dim3(256), 0, st, grad_out, weight, grad_x, C, H, W);

@@ -809,7 +809,8 @@ def test_depthwise_up_add_vs_conv_transpose(f, C, H, W):
     np.testing.assert_allclose(out.numpy(), ref.numpy(), rtol=1e-5, atol=1e-6)
 
 
-@pytest.mark.parametrize("f,C,H,W", [(2, 16, 12, 18), (4, 6, 7, 9), (2, 64, 8, 64)])
+@pytest.mark.parametrize("f,C,H,W", [(2, 16, 12, 18), (4, 6, 7, 9), (2, 64, 8, 64), (2, 5, 19, 134), (2, 3, 1, 2), (2, 4, 7, 10),
+                                     (2, 8, 33, 260)])
 def test_depthwise_up_add_backward_vs_autograd(f, C, H, W):
     from centerpoly_amd.models.networks.pose_dla_dcn import _DepthwiseUpAdd, fill_up_weights
     up = torch.nn.ConvTranspose2d(C, C, f * 2, stride=f, padding=f // 2, groups=C, bias=False)
