@@ -83,6 +83,8 @@ _SIGNATURES = {
     "cp_conv3x3_mfma_forward": (c_int32, [_P, _P, _P, _P, _P] + [c_int32] * 6 + [_P]),
     "cp_conv_mfma_weight_bytes": (c_size_t, [c_int32] * 3),
     "cp_conv_mfma_prepare": (c_int32, [_P, c_int32, c_int32, c_int32, c_int32, _P, _P]),
+    "cp_conv_mfma_prepare_blocks": (c_int32, [c_int32] * 3),
+    "cp_conv_mfma_prepare_batch": (c_int32, [_P, c_int32, c_int32, _P]),
     "cp_conv_mfma_forward": (c_int32, [_P, _P, c_int32, _P, _P, _P, _P] + [c_int32] * 6 + [_P]),
     "cp_conv_mfma_forward_strided": (c_int32, [_P, _P, c_int32, _P, _P, _P, _P] + [c_int32] * 7 + [_P]),
     "cp_conv_mfma_input_grad_relu_workspace_bytes": (c_size_t, [c_int32] * 4),
@@ -160,6 +162,12 @@ def stream():
 
 def workspace(nbytes, device):
     return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
+
+
+class ConvPrepareJob(ctypes.Structure):
+    """cp_conv_prepare_job of include/centerpoly_hip.h."""
+    _fields_ = [("weight", c_void_p), ("wperm", c_void_p), ("Cin", c_int32), ("Cout", c_int32), ("taps", c_int32),
+                ("transposed", c_int32), ("first_block", c_int32), ("reserved", c_int32)]
 
 
 class _ZeroPool(object):

@@ -48,10 +48,8 @@ constexpr unsigned OOB = 0xFFFFFFF0u;
 // Wsrc[m][k][tap] = W[k][m][taps - 1 - tap] with W = [K][M][taps].
 // transposed = 6 (the one-pass stride-2 input gradient, IG2): Wsrc[m][k][tap] = W[k][m][tap].
 // Rows past M (the tile count is rounded up to a multiple of 4) and k past K are zero.
-__global__ __launch_bounds__(256) void conv_mfma_wperm_kernel(const float* __restrict__ w, bf16x8* __restrict__ wp, int M,
-                                                              int K, int nchunk, int taps, int transposed, int total) {
-  const int e = blockIdx.x * 256 + threadIdx.x;
-  if (e >= total) return;
+__device__ __forceinline__ void wperm_element(const float* __restrict__ w, bf16x8* __restrict__ wp, int M, int K, int nchunk,
+                                              int taps, int transposed, int e) {
   const int lane = e & 63;
   int r = e >> 6;
   const int hl = r & 1;
@@ -76,6 +74,27 @@ __global__ __launch_bounds__(256) void conv_mfma_wperm_kernel(const float* __res
     o[j] = hl ? (__bf16)(v - (float)h) : h;
   }
   wp[e] = o;
+}
+
+__global__ __launch_bounds__(256) void conv_mfma_wperm_kernel(const float* __restrict__ w, bf16x8* __restrict__ wp, int M,
+                                                              int K, int nchunk, int taps, int transposed, int total) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e < total) wperm_element(w, wp, M, K, nchunk, taps, transposed, e);
+}
+
+// every job of a table in one launch (the training step's ~110 weight forms, permuted once after the optimizer's update
+// instead of one 4-microsecond launch per use): the workgroup finds its job by bisection over the jobs' first blocks
+__global__ __launch_bounds__(256) void conv_mfma_wperm_batch_kernel(const cp_conv_prepare_job* __restrict__ jobs, int njobs) {
+  int lo = 0, hi = njobs - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (jobs[mid].first_block <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const cp_conv_prepare_job j = jobs[lo];
+  const int nchunk = (j.Cin + KC - 1) / KC;
+  const int total = ((j.Cout + 63) / 64 * 4) * nchunk * j.taps * 2 * 64;
+  const int e = ((int)blockIdx.x - j.first_block) * 256 + threadIdx.x;
+  if (e < total) wperm_element(j.weight, (bf16x8*)j.wperm, j.Cout, j.Cin, nchunk, j.taps, j.transposed, e);
 }
 
 // sum over the 16 lanes of a DPP row (lanes 16 g .. 16 g + 15), left in every lane of the row
@@ -479,6 +498,16 @@ int cp_conv_mfma_prepare(const float* weight, int32_t Cin, int32_t Cout, int32_t
   const int total = tiles16(Cout) * nchunk * taps * 2 * 64;
   hipLaunchKernelGGL(conv_mfma_wperm_kernel, dim3((total + 255) / 256), dim3(256), 0, st, weight, (bf16x8*)wperm, Cout,
                      Cin, nchunk, taps, transposed, total);
+  return cp_launch_status();
+}
+
+int32_t cp_conv_mfma_prepare_blocks(int32_t Cin, int32_t Cout, int32_t taps) {
+  return (int32_t)((cp_conv_mfma_weight_bytes(Cin, Cout, taps) / 16 + 255) / 256);
+}
+
+int cp_conv_mfma_prepare_batch(const cp_conv_prepare_job* jobs_device, int32_t njobs, int32_t total_blocks, void* stream) {
+  CP_CHECK_ARG(jobs_device && njobs >= 1 && total_blocks >= 1);
+  hipLaunchKernelGGL(conv_mfma_wperm_batch_kernel, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, jobs_device, njobs);
   return cp_launch_status();
 }
 

@@ -10,6 +10,8 @@ products of split halves, and so does the weight gradient (cp_conv3x3_mfma_wgrad
 Shapes the kernel does not take (stride 2, 1x1, 7x7, fewer than 24 input channels, tiny maps) go to the direct
 kernel or the library.  `centerpoly_amd.arithmetic.configure("exact_f32")` turns the kernels off (library fp32)."""
 
+import weakref
+
 import torch
 import torch.nn.functional as F
 
@@ -57,12 +59,85 @@ def usable(conv, x):
     return False
 
 
+class _WeightBank(object):
+    """The permuted (split-bf16, fragment-ordered) forms of the model's convolution weights, refreshed by ONE launch per
+    optimizer step (cp_conv_mfma_prepare_batch) instead of one launch per use -- a training step uses ~110 forms.
+    A form enters the bank the first time a PARAMETER is prepared (temporaries -- weight slices, folded copies -- never
+    do); `refresh()` (the trainer calls it right after optimizer.step()) permutes every registered form and records the
+    parameters' versions; `get` serves a form only while the parameter is still at that version, so a weight changed
+    behind the bank's back (load_state_dict, manual edits) simply takes the per-use path until the next refresh."""
+
+    def __init__(self):
+        self.entries = {}          # (id(weight), cin, cout, code) -> [weakref, wp, version]
+        self.table = None          # (device tensor holding the job structs, njobs, total_blocks, keys in table order)
+
+    def get(self, weight, cin, cout, code):
+        if not isinstance(weight, torch.nn.Parameter):
+            return None
+        key = (id(weight), cin, cout, code)
+        e = self.entries.get(key)
+        if e is None or e[0]() is not weight:
+            taps = weight.shape[2] * weight.shape[3]
+            wp = torch.empty(_C.lib().cp_conv_mfma_weight_bytes(cin, cout, taps), dtype=torch.uint8, device=weight.device)
+            self.entries[key] = [weakref.ref(weight), wp, -1]
+            self.table = None
+            return None
+        return e[1] if e[2] == weight._version else None
+
+    def refresh(self):
+        import ctypes
+        L = _C.lib()
+        dead = [k for k, e in self.entries.items() if e[0]() is None]
+        for k in dead:
+            del self.entries[k]
+        if dead:
+            self.table = None
+        if not self.entries:
+            return
+        by_dev = {}
+        for k, e in self.entries.items():
+            by_dev.setdefault(e[1].device, []).append(k)
+        if self.table is None:
+            self.table = {}
+            for dev, keys in by_dev.items():
+                jobs = (_C.ConvPrepareJob * len(keys))()
+                blk = 0
+                for j, k in zip(jobs, keys):
+                    w = self.entries[k][0]()
+                    _, cin, cout, code = k
+                    j.weight, j.wperm = w.data_ptr(), self.entries[k][1].data_ptr()
+                    j.Cin, j.Cout, j.taps, j.transposed, j.first_block = cin, cout, w.shape[2] * w.shape[3], code, blk
+                    blk += L.cp_conv_mfma_prepare_blocks(cin, cout, j.taps)
+                host = torch.frombuffer(bytearray(bytes(jobs)), dtype=torch.uint8)
+                self.table[dev] = (host.to(dev), len(keys), blk, keys)
+        for dev, (tab, n, blocks, keys) in self.table.items():
+            with torch.cuda.device(dev):
+                _C.check(L.cp_conv_mfma_prepare_batch(_C.ptr(tab), n, blocks, _C.stream()), "cp_conv_mfma_prepare_batch")
+            for k in keys:
+                e = self.entries[k]
+                e[2] = e[0]()._version
+
+
+_BANK = _WeightBank()
+
+
+def refresh_weight_bank():
+    """Permute every registered convolution weight in one launch (call after optimizer.step())."""
+    if _ENABLED:
+        _BANK.refresh()
+
+
 def _prepare(weight, cin, cout, transposed):
+    """The permuted form of `weight` ([cout or cin][...][k][k]) for the MFMA kernels: transposed False / True, or the
+    kernel's mode code (6: the one-launch stride-2 input gradient)."""
+    code = int(transposed) if not isinstance(transposed, bool) else (1 if transposed else 0)
+    wp = _BANK.get(weight, cin, cout, code)
+    if wp is not None:
+        return wp
     L = _C.lib()
     taps = weight.shape[2] * weight.shape[3]
     wp = torch.empty(L.cp_conv_mfma_weight_bytes(cin, cout, taps), dtype=torch.uint8, device=weight.device)
-    _C.check(L.cp_conv_mfma_prepare(_C.ptr(weight), cin, cout, taps, 1 if transposed else 0, _C.ptr(wp), _C.stream()),
-             "cp_conv_mfma_prepare")
+    _C.check(L.cp_conv_mfma_prepare(_C.ptr(weight), cin, cout, taps, code, _C.ptr(wp), _C.stream()), "cp_conv_mfma_prepare")
     return wp
 
 
@@ -147,10 +222,8 @@ def s2_input_grad(xshape, weight, go):
         return None
     go = go.contiguous()
     gx = torch.empty(xshape, dtype=torch.float32, device=go.device)
-    nbytes = L.cp_conv_mfma_weight_bytes(cout, cin, 9)
     end = _C.kernel_timer.start(("conv3x3s2_igrad", cout, cin, Ho, Wo, B)) if _C.kernel_timer is not None else None
-    wp = torch.empty(nbytes, dtype=torch.uint8, device=go.device)
-    _C.check(L.cp_conv_mfma_prepare(_C.ptr(weight), cout, cin, 9, 6, _C.ptr(wp), _C.stream()), "cp_conv_mfma_prepare")
+    wp = _prepare(weight, cout, cin, 6)
     _C.check(L.cp_conv3x3_s2_input_grad(_C.ptr(go), _C.ptr(wp), None, _C.ptr(gx), B, cin, H, W, cout, _C.stream()),
              "cp_conv3x3_s2_input_grad")
     if end is not None:

@@ -414,7 +414,10 @@ class Tree(nn.Module):
             residual = None
             if self.training:                 # only its BatchNorm running stats are observable
                 with torch.no_grad():
-                    self.project(bottom)
+                    if bottom.is_cuda:            # (same kernels as the live projections)
+                        bn_act(self.project[1], conv_train(self.project[0], bottom), relu=False)
+                    else:
+                        self.project(bottom)
         elif _use_folded(self):
             residual = _conv_folded(bottom, self.project[0], self._folded)
         else:                                  # conv1x1 + BatchNorm (no activation), fused BN in training

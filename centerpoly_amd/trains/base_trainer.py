@@ -16,6 +16,7 @@ import time
 import torch
 import torch.distributed as dist
 
+from ..models.networks import conv3x3
 from ..utils.utils import AverageMeter
 
 
@@ -65,6 +66,7 @@ class BaseTrainer(object):
                 torch.nn.utils.clip_grad_norm_(self.model_with_loss.parameters(),
                                                float(self.opt.clip_value))
             self.optimizer.step()
+            conv3x3.refresh_weight_bank()        # the MFMA kernels' weight forms for the next step, in one launch
         return output, loss, loss_stats
 
     def run_epoch(self, phase, epoch, data_loader):

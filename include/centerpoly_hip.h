@@ -241,6 +241,17 @@ int cp_conv3x3_mfma_forward(const float* x, const void* wperm, const float* bias
 size_t cp_conv_mfma_weight_bytes(int32_t Cin, int32_t Cout, int32_t taps);
 int cp_conv_mfma_prepare(const float* weight, int32_t Cin, int32_t Cout, int32_t taps, int32_t transposed, void* wperm,
                          void* stream);
+/* The same for a whole table of weights in ONE launch (a training step uses ~110 forms -- every convolution's forward and
+ * transposed one -- each a 4-microsecond launch of its own when prepared per use): `jobs` lives in DEVICE memory, job i's
+ * workgroups are first_block .. first_block + cp_conv_mfma_prepare_blocks(Cin, Cout, taps) - 1 (first_block ascending,
+ * job 0 at 0), total_blocks their sum.  Cin / Cout / transposed as for cp_conv_mfma_prepare. */
+typedef struct cp_conv_prepare_job {
+  const float* weight;
+  void* wperm;
+  int32_t Cin, Cout, taps, transposed, first_block, reserved;
+} cp_conv_prepare_job;
+int32_t cp_conv_mfma_prepare_blocks(int32_t Cin, int32_t Cout, int32_t taps);
+int cp_conv_mfma_prepare_batch(const cp_conv_prepare_job* jobs_device, int32_t njobs, int32_t total_blocks, void* stream);
 int cp_conv_mfma_forward(const float* const* xs, const int32_t* cs, int32_t nsrc, const void* wperm, const float* bias,
                          const float* residual, float* out, int32_t B, int32_t H, int32_t W, int32_t Cout,
                          int32_t taps, int32_t relu, void* stream);

@@ -427,6 +427,42 @@ def test_concatenated_1x1_training_node(cs):
         assert a.is_contiguous() and _rel(a, b) <= 1e-4
 
 
+def test_weight_bank_serves_only_current_versions():
+    """conv3x3's weight bank (one cp_conv_mfma_prepare_batch launch per optimizer step): a parameter's permuted forms
+    are served from the bank only at the version they were permuted at; an in-place change falls back to the per-use
+    path until the next refresh; temporaries never enter the bank."""
+    from centerpoly_amd.models.networks import conv3x3
+    conv = torch.nn.Conv2d(64, 64, 3, padding=1, bias=False).to(DEV)
+    conv2 = torch.nn.Conv2d(64, 128, 3, stride=2, padding=1, bias=False).to(DEV)
+    x = _t("wbx", (2, 64, 128, 136)).requires_grad_(True)
+    ref = lambda c: F.conv2d(x.detach().double(), c.weight.detach().double(), stride=c.stride, padding=1)
+
+    def run():
+        y, y2 = conv3x3.conv_raw(conv, x), conv3x3.conv_raw(conv2, x)
+        gx, = torch.autograd.grad([y.sum() + y2.sum()], [x])
+        return y, y2, gx
+    y, y2, gx0 = run()                                           # registers the forms (forward, transposed, stride-2 gradient)
+    assert _rel(y, ref(conv)) <= TOL and _rel(y2, ref(conv2)) <= TOL
+    assert conv3x3._BANK.get(conv.weight, 64, 64, 0) is None     # registered, not yet permuted
+    conv3x3.refresh_weight_bank()
+    for code, (ci, co, w) in {0: (64, 64, conv.weight), 1: (64, 64, conv.weight), 6: (128, 64, conv2.weight)}.items():
+        assert conv3x3._BANK.get(w, ci, co, code) is not None, code
+    y, y2, gx1 = run()                                           # served from the bank
+    assert _rel(y, ref(conv)) <= TOL and _rel(y2, ref(conv2)) <= TOL and torch.equal(gx0, gx1)
+    with torch.no_grad():
+        conv.weight.mul_(-1.5)
+        conv2.weight.add_(0.01)
+    assert conv3x3._BANK.get(conv.weight, 64, 64, 0) is None     # stale: per-use path
+    y, y2, gx2 = run()
+    assert _rel(y, ref(conv)) <= TOL and _rel(y2, ref(conv2)) <= TOL and not torch.equal(gx1, gx2)
+    conv3x3.refresh_weight_bank()
+    y, y2, gx3 = run()
+    assert _rel(y, ref(conv)) <= TOL and _rel(y2, ref(conv2)) <= TOL and torch.equal(gx2, gx3)
+    n = len(conv3x3._BANK.entries)
+    conv3x3._prepare(conv.weight[:, :32].contiguous(), 32, 64, False)      # a temporary: not registered
+    assert len(conv3x3._BANK.entries) == n
+
+
 def test_stride_2_autograd_wrapper():
     """conv_raw on a stride-2 3x3 convolution: forward and input gradient from the MFMA kernel, weight gradient from
     the library."""
