@@ -176,3 +176,70 @@ def test_hourglass_full_size_properties():
                                        rep="polar", return_inds=True)
     assert tuple(dets.shape) == (1, 128, 2 * 24 + 7) and torch.isfinite(dets).all()
     assert int(inds.min()) >= 0 and int(inds.max()) < 256 * 512 and int(clses.min()) >= 0 and int(clses.max()) < 8
+
+
+@pytest.mark.parametrize("shape", [(4, 32, 64, 512, 1024), (4, 16, 32, 1024, 2048)], ids=["level2 32<-64", "level1 16<-32"])
+def test_full_size_stride_2_input_gradient(shape):
+    """cp_conv3x3_s2_input_grad at the training launches: every element written, linear in grad_out, bit-identical rerun,
+    the adjoint identity <grad_in, x> = <grad_out, conv_s2(x)> against the kernel's own stride-2 forward, and equality
+    with the library's fp32 conv_transpose on a band of rows."""
+    B, ci, co, H, W = shape
+    L = _C.lib()
+    Ho, Wo = H // 2, W // 2
+    w, go = _t("s2w%s" % (shape,), (co, ci, 3, 3), 0.05), _t("s2go%s" % (shape,), (B, co, Ho, Wo))
+    wp = torch.empty(L.cp_conv_mfma_weight_bytes(co, ci, 9), dtype=torch.uint8, device=DEV)
+    _C.check(L.cp_conv_mfma_prepare(P(w), co, ci, 9, 6, P(wp), _C.stream()), "prepare")
+
+    def igrad(g, res=None):
+        out = torch.full((B, ci, H, W), float("nan"), device=DEV) if res is None else res
+        _C.check(L.cp_conv3x3_s2_input_grad(P(g), P(wp), P(res), P(out), B, ci, H, W, co, _C.stream()), "igrad")
+        return out
+    g1 = igrad(go)
+    assert torch.isfinite(g1).all() and torch.equal(g1, igrad(go))
+    g2 = igrad(go * 0.5)
+    assert (g2 - 0.5 * g1).abs().max().item() <= 1e-6 * g1.abs().max().item()
+    acc = igrad(go, res=g1.clone())                              # accumulate onto itself in place: 2 x
+    assert (acc - 2 * g1).abs().max().item() <= 1e-6 * g1.abs().max().item()
+    # band: rows [2 y0, 2 y0 + 2 r) of grad_in depend on grad_out rows y0 - 1 .. y0 + r
+    y0, r = 37, 16
+    ref = F.conv_transpose2d(go[:, :, y0 - 1:y0 + r + 1], w, stride=2, padding=1, output_padding=1)
+    got = g1[:, :, 2 * y0:2 * y0 + 2 * r]
+    refb = ref[:, :, 2:2 + 2 * r]
+    assert (got - refb).abs().max().item() <= TOL * refb.abs().max().item()
+    if ci >= 24:                                                 # adjoint against the kernel's own stride-2 forward
+        x = _t("s2x%s" % (shape,), (B, ci, H, W))
+        wpf = torch.empty(L.cp_conv_mfma_weight_bytes(ci, co, 9), dtype=torch.uint8, device=DEV)
+        _C.check(L.cp_conv_mfma_prepare(P(w), ci, co, 9, 0, P(wpf), _C.stream()), "prepare")
+        y = torch.empty((B, co, Ho, Wo), device=DEV)
+        ptrs, chans = (ctypes.c_void_p * 1)(x.data_ptr()), (ctypes.c_int32 * 1)(ci)
+        _C.check(L.cp_conv_mfma_forward_strided(ptrs, chans, 1, P(wpf), None, None, P(y), B, H, W, co, 9, 2, 0, _C.stream()), "fwd")
+        lhs, rhs = (g1.double() * x.double()).sum().item(), (go.double() * y.double()).sum().item()
+        assert abs(lhs - rhs) <= 1e-4 * abs(rhs)
+
+
+def test_full_size_masked_head_gradient():
+    """cp_conv_mfma_input_grad_relu at the heads' training launch (4 x 256 channels @256x512 from an 8-channel head):
+    masked exactly where y <= 0, equal to the library's gradient elsewhere on a band, bias gradient = the channel sums
+    of what it wrote, bit-identical rerun of the map."""
+    B, c1, c2, H, W = 4, 256, 8, 256, 512
+    L = _C.lib()
+    w2, go = _t("mhw", (c2, c1, 1, 1), 0.1), _t("mhgo", (B, c2, H, W))
+    y = torch.relu(_t("mhy", (B, c1, H, W)))
+    wp = torch.empty(L.cp_conv_mfma_weight_bytes(c2, c1, 1), dtype=torch.uint8, device=DEV)
+    _C.check(L.cp_conv_mfma_prepare(P(w2), c2, c1, 1, 1, P(wp), _C.stream()), "prepare")
+    ws = torch.empty(L.cp_conv_mfma_input_grad_relu_workspace_bytes(B, c1, H, W), dtype=torch.uint8, device=DEV)
+
+    def run():
+        g = torch.full((B, c1, H, W), float("nan"), device=DEV)
+        gb = torch.zeros(c1, device=DEV)
+        _C.check(L.cp_conv_mfma_input_grad_relu(P(go), P(wp), P(y), P(g), P(gb), B, c1, H, W, c2, 1, P(ws), ws.numel(),
+                                                _C.stream()), "igrad_relu")
+        return g, gb
+    g, gb = run()
+    assert torch.isfinite(g).all() and torch.equal(g, run()[0])
+    assert (g[y <= 0] == 0).all()
+    y0, r = 101, 32
+    ref = F.conv_transpose2d(go[:, :, y0:y0 + r], w2) * (y[:, :, y0:y0 + r] > 0)
+    assert (g[:, :, y0:y0 + r] - ref).abs().max().item() <= TOL * ref.abs().max().item()
+    sums = g.double().sum(dim=(0, 2, 3))
+    assert (gb.double() - sums).abs().max().item() <= 1e-5 * sums.abs().max().item()
