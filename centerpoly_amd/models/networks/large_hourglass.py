@@ -207,7 +207,7 @@ class exkp(nn.Module):
             for m in self.modules():
                 if hasattr(m, "_folded"):
                     m._folded = None
-                for k in [k for k in m.__dict__ if k.startswith(("_mfma_wperm", "_heads_wperm", "_dcn_fwd_ws", "_dcn_fused_ws"))]:
+                for k in [k for k in m.__dict__ if k.startswith(("_mfma_wperm", "_heads_wperm", "_stem_wperm", "_dcn_fwd_ws", "_dcn_fused_ws"))]:
                     del m.__dict__[k]          # permuted inference weights / DCN workspaces of the folded tensors
             self._heads_cat = None
             self._inter_folded = None

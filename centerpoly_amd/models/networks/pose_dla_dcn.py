@@ -152,6 +152,8 @@ def _conv_folded(x, conv, wb, relu=False, residual=None):
             return y
     if x.is_cuda:
         y = conv3x3_infer(x, conv, wb[0], wb[1], residual, relu, conv=conv)
+        if y is None and residual is None:
+            y = conv3x3.stem_infer(x, conv, wb[0], wb[1], relu)      # the Hourglass' 7x7 / stride 2 stem
         if y is not None:
             return y
     if not x.is_cuda:

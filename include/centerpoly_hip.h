@@ -261,6 +261,17 @@ int cp_conv_mfma_forward(const float* const* xs, const int32_t* cs, int32_t nsrc
 int cp_conv_mfma_forward_strided(const float* const* xs, const int32_t* cs, int32_t nsrc, const void* wperm,
                                  const float* bias, const float* residual, float* out, int32_t B, int32_t H, int32_t W,
                                  int32_t Cout, int32_t taps, int32_t stride, int32_t relu, void* stream);
+/* The Hourglass stem: 7x7 / stride 2 / pad 3 convolution of a 3-channel image (+ bias, + ReLU) on the bf16 matrix cores
+ * (split-bf16 x3, the arithmetic above) -- `pre = convolution(7, 3, 128, stride=2)`,
+ * src/lib/models/networks/large_hourglass.py:287-290 (cuDNN in the reference; BatchNorm folded by the caller):
+ *   out[b][co][y][x] = act(bias[co] + sum w[co][ci][ky][kx] * x[b][ci][2 y - 3 + ky][2 x - 3 + kx])
+ * x [B][3][H][W], weight [Cout][3][7][7] (prepared once into wperm), out [B][Cout][(H - 1) / 2 + 1][(W - 1) / 2 + 1]. */
+int cp_conv7x7s2_c3_supported(int32_t Cout, int32_t H, int32_t W);
+size_t cp_conv7x7s2_c3_weight_bytes(int32_t Cout);
+int cp_conv7x7s2_c3_prepare(const float* weight, int32_t Cout, void* wperm, void* stream);
+int cp_conv7x7s2_c3_forward(const float* x, const void* wperm, const float* bias, float* out, int32_t B, int32_t H,
+                            int32_t W, int32_t Cout, int32_t relu, void* stream);
+
 /* Input gradient of a stride-1 convolution (3x3 / pad 1 or 1x1) whose INPUT was the output y of a bias + ReLU epilogue
  * (the heads' Conv2d(3x3, bias) -> ReLU -> Conv2d(1x1), src/lib/models/networks/pose_dla_dcn.py:445-462), with that
  * ReLU's backward and its bias gradient in the kernel's epilogue (threshold_backward + the bias sum in the reference):
