@@ -48,6 +48,15 @@ cp gpurun_out/pmc_bwd_${tag}_data/summary.txt $P/${tag}_dcn_bwd_data_pmc_summary
 PMC_WHAT=weight tools/run_pmc_bwd.sh ${tag}_weight >> $log 2>&1
 cp gpurun_out/pmc_bwd_${tag}_weight/summary.txt $P/${tag}_dcn_bwd_weight_pmc_summary.txt
 
+step "PMC: counters of the MFMA convolution (64->64 @256x512 x4)"
+PMC_SCRIPT=tools/pmc_conv.py tools/run_pmc_fwd.sh ${tag}_conv >> $log 2>&1
+cp gpurun_out/pmc_fwd_${tag}_conv/summary.txt $P/${tag}_conv_mfma_pmc_summary.txt
+
+step "probes: convolution ablations / in-kernel stamps / stride-2 input gradient"
+timeout -k 10 300 python3 tools/probe_conv_ablate.py > $P/${tag}_conv_mfma_ablations.txt 2>> $log
+timeout -k 10 300 python3 tools/probe_conv_stamp.py > $P/${tag}_conv_mfma_stamps.txt 2>> $log
+timeout -k 10 300 python3 tools/probe_s2_igrad.py > $P/${tag}_conv_s2_igrad_probe.txt 2>> $log
+
 step "probes: region kernel phases, ablations, offset fields; backward launch times"
 timeout -k 10 300 python3 tools/probe_region_stamp.py > $P/${tag}_dcn_fwd_region_stamps.txt 2>> $log
 timeout -k 10 300 python3 tools/probe_region_ablate.py > $P/${tag}_dcn_fwd_region_ablations.txt 2>> $log

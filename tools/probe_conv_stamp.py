@@ -1,5 +1,6 @@
 """GPU probe: phase durations inside the MFMA convolution (diagnostic build libcp_cvstamp.so: wave 0 of every workgroup
-writes s_memtime deltas over out[]).  Per chunk: wait at the top barrier | stage (loads + split + LDS stores) | barrier | taps."""
+writes s_memtime deltas past out[]).  Per chunk: stage (loads + split + LDS stores) | barrier | taps | next chunk's top barrier.
+The in-kernel clock (s_memtime / s_memrealtime) shows what the chip holds under this kernel's load."""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -23,7 +24,7 @@ for (B, ci, co, H, W, nwg) in [(4, 64, 64, 256, 512, 512), (1, 64, 64, 256, 512,
     s = out[B].flatten()[:B * nwg * 16].view(-1, 16).cpu().numpy()
     s = s[s[:, 13] > 0]
     n = int(s[0, 13])
-    names = ["prologue"] + sum([["c%d top barrier" % c, "c%d stage" % c, "c%d barrier" % c, "c%d taps" % c] for c in range(4)], [])
+    names = ["prologue"] + sum([["c%d stage" % c, "c%d barrier" % c, "c%d taps" % c, "c%d top barrier" % (c + 1)] for c in range(4)], [])
     tot = s[:, :13].sum(1)
     mhz = np.median(tot / (s[:, 14] / 100.0))
     print("B%d %d->%d @%dx%d: %d workgroups stamped, %d stamps, in-kernel clock %.0f MHz" % (B, ci, co, H, W, len(s), n, mhz))
