@@ -197,6 +197,7 @@ HEADS_SOURCES = ("heads_fused.hip", "cp_common.h")
 
 
 DCN_FWD_SOURCES = ("dcn_fwd.hip", "dcn_fwd_region.hip", "cp_common.h")
+DCN_BWD_SOURCES = ("dcn_bwd.hip", "dcn_bwd_data.hip", "dcn_bwd_weight.hip", "cp_common.h")
 
 
 def kernel_revision(sources=DCN_FWD_SOURCES):
@@ -230,6 +231,24 @@ def measured_traffic(cin, cout, h, w, nb, prof_name="dcn_fwd_pmc.json", sources=
                      "FETCH_SIZE correction applied, kernel revision %s" % (d.get("command", "?"), d["kernel_rev"])
 
 
+def measured_traffic_bwd(tag, cin, cout, h, w, nb):
+    """HBM bytes per launch of a DCNv2 backward family (main kernel + its reduce) from profiles/dcn_bwd_pmc.json
+    (tools/pmc_bwd_traffic.py over tools/run_pmc_bwd.sh): only at the CURRENT kernel revision and launch shape."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "dcn_bwd_pmc.json")) as fh:
+            d = json.load(fh)
+    except (OSError, ValueError):
+        return None, "no PMC file"
+    if d.get("kernel_rev") != kernel_revision(DCN_BWD_SOURCES):
+        return None, "PMC passes are from another kernel revision (%s): not reported" % d.get("kernel_rev")
+    v = d.get("layers", {}).get("%dx%dx%dx%dx%d" % (nb, cin, cout, h, w), {}).get(tag)
+    if v is None:
+        return None, "launch shape not in the PMC file"
+    return float(v), "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over %s, same launch shape (not the bench's own " \
+                     "tensors); FETCH_SIZE doubled: an upper bound for these kernels' narrow loads; kernel revision %s" \
+                     % (d.get("inputs", "?"), d["kernel_rev"])
+
+
 def dcn_roofline(summary, tag="dcn_fwd", fwd_contraction="auto"):
     """Dominant launch of one DCNv2 kernel family: the layer shape with the largest total time in the
     timed region.  Algorithmic bytes / FLOPs per launch: SURVEY.md 8(d); the backward kernels read
@@ -249,9 +268,11 @@ def dcn_roofline(summary, tag="dcn_fwd", fwd_contraction="auto"):
     elif tag == "dcn_bwd_data":     # reads x, offset/mask, weight, grad_out; writes grad_x, grad_offset/mask
         alg_bytes = 4.0 * (nb * (2 * cin + 2 * 27 + cout) * h * w + 9 * cin * cout)
         alg_flops, name = gemm_flops, "dcn_v2_backward (data: grad_x, grad_offset, grad_mask)"
+        traffic, traffic_src = measured_traffic_bwd(tag, cin, cout, h, w, nb)
     else:                           # reads x, offset/mask, grad_out; writes grad_weight
         alg_bytes = 4.0 * (nb * (cin + 27 + cout) * h * w + 9 * cin * cout)
         alg_flops, name = gemm_flops, "dcn_v2_backward (weight)"
+        traffic, traffic_src = measured_traffic_bwd(tag, cin, cout, h, w, nb)
     layer = "%s %d->%d @%dx%d" % (name, cin, cout, h, w) + (" x%d images" % nb if nb != 1 else "")
     common = {"traffic": traffic, "traffic_source": traffic_src, "kernel": layer, "avg_launch_us": avg_s * 1e6,
               "launches": summary[key]["launches"]}

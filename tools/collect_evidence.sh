@@ -47,6 +47,7 @@ PMC_WHAT=data tools/run_pmc_bwd.sh ${tag}_data >> $log 2>&1
 cp gpurun_out/pmc_bwd_${tag}_data/summary.txt $P/${tag}_dcn_bwd_data_pmc_summary.txt
 PMC_WHAT=weight tools/run_pmc_bwd.sh ${tag}_weight >> $log 2>&1
 cp gpurun_out/pmc_bwd_${tag}_weight/summary.txt $P/${tag}_dcn_bwd_weight_pmc_summary.txt
+python3 tools/pmc_bwd_traffic.py $P/${tag}_dcn_bwd_data_pmc_summary.txt $P/${tag}_dcn_bwd_weight_pmc_summary.txt $P/dcn_bwd_pmc.json >> $log 2>&1
 
 step "PMC: counters of the MFMA convolution (64->64 @256x512 x4)"
 PMC_SCRIPT=tools/pmc_conv.py tools/run_pmc_fwd.sh ${tag}_conv >> $log 2>&1

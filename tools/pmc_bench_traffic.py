@@ -17,9 +17,10 @@ import bench
 SHAPES = {131072: (1, 64, 64, 256, 512), 524288: (1, 64, 64, 256, 512)}
 
 
-# the fused heads' convolution of the same step (conv_mfma_kernel<4, 2, 9, 1>: 512 tiles x 16 output-channel tiles
-# x 256 threads), the dominant launch of the split-bf16 convolution at inference
-CONV_SHAPES = {512 * 16 * 256: (1, 64, 1024, 256, 512)}
+# the dominant launch shape of the split-bf16 3x3 convolution at inference (bench.py's roofline_conv3x3):
+# 128 -> 128 @128x256 = conv_mfma_kernel<2, 2, 9, ...>, 128 tiles x 4 output-channel tiles x 256 threads
+CONV_SHAPES = {128 * 4 * 256: (1, 128, 128, 128, 256)}
+CONV_KERNEL = "conv_mfma_kernel<2, 2, 9"
 
 
 def avg(dirname, counter, match="dcn_fwd"):
@@ -53,7 +54,7 @@ print(json.dumps(out))
 
 # ---- the same two passes reduced for the MFMA convolution (wide coalesced streams: the doubling applies) ----
 if len(sys.argv) > 4:
-    fetch, write = avg(sys.argv[1], "FETCH_SIZE", "conv_mfma_kernel<4, 2, 9"), avg(sys.argv[2], "WRITE_SIZE", "conv_mfma_kernel<4, 2, 9")
+    fetch, write = avg(sys.argv[1], "FETCH_SIZE", CONV_KERNEL), avg(sys.argv[2], "WRITE_SIZE", CONV_KERNEL)
     layers, raw = {}, {}
     for grid, shape in CONV_SHAPES.items():
         if grid in fetch and grid in write:
