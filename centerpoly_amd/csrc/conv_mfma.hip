@@ -158,7 +158,13 @@ __global__ __launch_bounds__(256 * KS, KS > 1 ? 4 : 2) void conv_mfma_kernel(CvA
   const int grp = __builtin_amdgcn_readfirstlane(threadIdx.x >> 8);
   bf16x8* Xs = Xall + grp * 2 * PLANE;
   const int tid = threadIdx.x & 255, lane = tid & 63, wid = tid >> 6, g = lane >> 4, c = lane & 15;
-  const int cot = blockIdx.x % a.ncot, tile = blockIdx.x / a.ncot;
+  // XCD-aware order: the hardware deals consecutive workgroups round-robin over the 8 XCDs (each with its own L2), so
+  // the ncot workgroups that stage the SAME input tile (one per output-channel tile) would fetch it through 4 different
+  // L2s -- 4.2x the input's bytes on the fabric side at 128 -> 128 (PMC FETCH_SIZE).  Workgroup w takes the logical index
+  // (w % 8) * (n / 8) + w / 8: logical neighbours share an XCD, and with it the tile's rows in L2.
+  int lw = blockIdx.x;
+  if ((gridDim.x & 7) == 0) lw = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  const int cot = lw % a.ncot, tile = lw / a.ncot;
   const int x0 = (tile % a.tiles_x) * TW, y0 = (tile / a.tiles_x) * TH, b = blockIdx.y;
   const int HW = a.H * a.W;                                  // input plane size
 
