@@ -8,7 +8,7 @@ from centerpoly_amd import _C
 here = os.path.dirname(_C.LIB_PATH)
 P = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
 vp, i32 = ctypes.c_void_p, ctypes.c_int32
-BITS = {1000: "previous build (tap mask + strided placement)", 1: "no W reloads", 2: "no staging loads", 4: "no B ds_reads", 8: "no MFMA", 16: "no staging"}
+BITS = {1: "no W reloads", 2: "no staging loads", 4: "no B ds_reads", 8: "no MFMA", 16: "no staging"}
 only = [int(v) for v in sys.argv[1:]]
 libs = [(0, _C.LIB_PATH)] + sorted((int(os.path.basename(p)[12:-3]), p) for p in glob.glob(os.path.join(here, "libcp_cvabl_*.so")))
 SHAPES = [(1, 64, 64, 256, 512), (1, 128, 128, 128, 256), (1, 256, 256, 64, 128), (1, 512, 512, 32, 64), (4, 64, 64, 256, 512),
@@ -37,5 +37,5 @@ for (B, ci, co, H, W) in SHAPES:
             call()
         e1.record(); torch.cuda.synchronize()
         t = e0.elapsed_time(e1) / 40
-        nm = BITS[mask] if mask >= 1000 else (" + ".join(v for k, v in BITS.items() if mask & k) or "full")
+        nm = " + ".join(v for k, v in BITS.items() if mask & k) or "full"
         print("B%d %3d->%3d %3dx%3d  %-34s %.1f us  (%.0f TF/s fp32-equivalent)" % (B, ci, co, H, W, nm, t * 1e3, 2.0 * B * ci * co * 9 * H * W / t / 1e9), flush=True)
