@@ -256,6 +256,25 @@ def stem_infer(x, conv, w, bias, relu):
     return out
 
 
+def s2_weight_grad(x, weight, go):
+    """Weight gradient of a 3x3 / stride 2 / pad 1 convolution (cp_conv3x3_s2_wgrad); None where the kernel does not take
+    the shape or the MFMA weight gradients are switched off."""
+    L = _C.lib()
+    B, cin, H, W = x.shape
+    cout = weight.shape[0]
+    if not (_ENABLED and _WGRAD and x.is_cuda and x.dtype == torch.float32 and tuple(weight.shape[2:]) == (3, 3)
+            and cin >= MIN_CIN and L.cp_conv3x3_s2_wgrad_supported(cin, cout, H, W)
+            and tuple(go.shape) == (B, cout, (H - 1) // 2 + 1, W // 2)):
+        return None
+    gw = _C.zeros(weight.shape, weight.device)
+    end = _C.kernel_timer.start(("conv3x3s2_wgrad", cin, cout, H, W, B)) if _C.kernel_timer is not None else None
+    _C.check(L.cp_conv3x3_s2_wgrad(_C.ptr(x), _C.ptr(go.contiguous()), _C.ptr(gw), B, cin, H, W, cout, _C.stream()),
+             "cp_conv3x3_s2_wgrad")
+    if end is not None:
+        end.record()
+    return gw
+
+
 class _Conv3x3Fn(torch.autograd.Function):
     """Training: forward and input gradient on the matrix cores (the input gradient is the same kernel
     over grad_out with the transposed, flipped weights); weight gradient by cp_conv3x3_mfma_wgrad."""
@@ -278,8 +297,11 @@ class _Conv3x3Fn(torch.autograd.Function):
                 gx = s2_input_grad(x.shape, weight, go)
                 if gx is None:
                     gx = torch.nn.grad.conv2d_input(x.shape, weight, go, stride=ctx.stride, padding=1)
-            gw = torch.nn.grad.conv2d_weight(x, weight.shape, go, stride=ctx.stride, padding=1) \
-                if ctx.needs_input_grad[1] else None
+            gw = None
+            if ctx.needs_input_grad[1]:
+                gw = s2_weight_grad(x, weight, go)
+                if gw is None:
+                    gw = torch.nn.grad.conv2d_weight(x, weight.shape, go, stride=ctx.stride, padding=1)
             return gx, gw, None
         return grads(x, weight, go, ctx.needs_input_grad[0], ctx.needs_input_grad[1], min_k=MIN_CIN) + (None,)
 

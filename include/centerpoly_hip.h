@@ -261,6 +261,15 @@ int cp_conv_mfma_forward(const float* const* xs, const int32_t* cs, int32_t nsrc
 int cp_conv_mfma_forward_strided(const float* const* xs, const int32_t* cs, int32_t nsrc, const void* wperm,
                                  const float* bias, const float* residual, float* out, int32_t B, int32_t H, int32_t W,
                                  int32_t Cout, int32_t taps, int32_t stride, int32_t relu, void* stream);
+/* Weight gradient of a 3x3 / stride 2 / pad 1 convolution (the first convolution of DLA levels 2-5,
+ * src/lib/models/networks/pose_dla_dcn.py:32-40; cuDNN's backward-filter in the reference), same arithmetic:
+ *   gw[co][ci][ky][kx] += sum_{b,i,j} grad_out[b][co][i][j] * x[b][ci][2 i + ky - 1][2 j + kx - 1]
+ * x [B][Cin][H][W], grad_out [B][Cout][(H - 1) / 2 + 1][W / 2]; gw [Cout][Cin][3][3] is ACCUMULATED into (float atomics:
+ * zero it first).  Needs W % 8 == 0; cp_conv3x3_s2_wgrad_supported tells, else CP_EUNSUPPORTED. */
+int cp_conv3x3_s2_wgrad_supported(int32_t Cin, int32_t Cout, int32_t H, int32_t W);
+int cp_conv3x3_s2_wgrad(const float* x, const float* grad_out, float* gw, int32_t B, int32_t Cin, int32_t H, int32_t W,
+                        int32_t Cout, void* stream);
+
 /* The Hourglass stem: 7x7 / stride 2 / pad 3 convolution of a 3-channel image (+ bias, + ReLU) on the bf16 matrix cores
  * (split-bf16 x3, the arithmetic above) -- `pre = convolution(7, 3, 128, stride=2)`,
  * src/lib/models/networks/large_hourglass.py:287-290 (cuDNN in the reference; BatchNorm folded by the caller):

@@ -483,9 +483,27 @@ def test_hourglass_stem_kernel(cfg):
         assert torch.isfinite(out).all() and _rel(out, ref) <= TOL
 
 
+@pytest.mark.parametrize("shape", [(2, 32, 64, 40, 72), (1, 64, 128, 17, 40), (1, 128, 256, 64, 128), (2, 256, 512, 32, 64),
+                                   (1, 27, 70, 12, 136), (4, 32, 64, 128, 256)],
+                         ids=["32->64", "odd height", "128->256", "256->512", "ragged channels", "level2 size / 4"])
+def test_stride_2_weight_gradient(shape):
+    """cp_conv3x3_s2_wgrad: the weight gradient of a 3x3 / stride 2 / pad 1 convolution against torch.nn.grad.conv2d_weight
+    in float64; accumulates into gw."""
+    B, ci, co, H, W = shape
+    L = _C.lib()
+    assert L.cp_conv3x3_s2_wgrad_supported(ci, co, H, W)
+    Ho, Wo = (H - 1) // 2 + 1, W // 2
+    x, go = _t("s2wx%s" % (shape,), (B, ci, H, W)), _t("s2wgo%s" % (shape,), (B, co, Ho, Wo))
+    gw = torch.zeros((co, ci, 3, 3), device=DEV)
+    _C.check(L.cp_conv3x3_s2_wgrad(P(x), P(go), P(gw), B, ci, H, W, co, _C.stream()), "s2 wgrad")
+    ref = torch.nn.grad.conv2d_weight(x.double(), (co, ci, 3, 3), go.double(), stride=2, padding=1)
+    assert torch.isfinite(gw).all() and _rel(gw, ref) <= 1e-4
+    _C.check(L.cp_conv3x3_s2_wgrad(P(x), P(go), P(gw), B, ci, H, W, co, _C.stream()), "s2 wgrad")      # accumulates
+    assert _rel(gw, 2 * ref) <= 1e-4
+
+
 def test_stride_2_autograd_wrapper():
-    """conv_raw on a stride-2 3x3 convolution: forward and input gradient from the MFMA kernel, weight gradient from
-    the library."""
+    """conv_raw on a stride-2 3x3 convolution: forward, input gradient and weight gradient from the MFMA kernels."""
     from centerpoly_amd.models.networks import conv3x3
     conv = torch.nn.Conv2d(64, 128, 3, stride=2, padding=1, bias=False).to(DEV)
     x = _t("s2ax", (4, 64, 64, 128)).requires_grad_(True)

@@ -17,3 +17,15 @@ for (B,ci,co,H,W) in [(4,32,64,512,1024),(4,64,128,256,512),(4,128,256,128,256),
         for _ in range(20): f()
         e1.record(); torch.cuda.synchronize()
         print((B,ci,co,H,W), name, "%.1f us" % (e0.elapsed_time(e1)*50), flush=True)
+    # weight gradient of the same layer: own kernel vs the library
+    x = torch.randn(B, ci, H, W, device="cuda"); gw = torch.zeros_like(w)
+    def own_w(): L.cp_conv3x3_s2_wgrad(P(x), P(go), P(gw), B, ci, H, W, co, _C.stream())
+    def lib_w(): return torch.nn.grad.conv2d_weight(x, w.shape, go, stride=2, padding=1)
+    if L.cp_conv3x3_s2_wgrad_supported(ci, co, H, W) and ci >= 24:
+        for name, f in (("wgrad own", own_w), ("wgrad lib", lib_w)):
+            for _ in range(3): f()
+            torch.cuda.synchronize(); e0=torch.cuda.Event(enable_timing=True); e1=torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(20): f()
+            e1.record(); torch.cuda.synchronize()
+            print((B,ci,co,H,W), name, "%.1f us" % (e0.elapsed_time(e1)*50), flush=True)
