@@ -19,8 +19,9 @@ SHAPES = {131072: (1, 64, 64, 256, 512), 524288: (1, 64, 64, 256, 512)}
 
 # the dominant launch shape of the split-bf16 3x3 convolution at inference (bench.py's roofline_conv3x3):
 # 128 -> 128 @128x256 = conv_mfma_kernel<2, 2, 9, ...>, 128 tiles x 4 output-channel tiles x 256 threads
-CONV_SHAPES = {128 * 4 * 256: (1, 128, 128, 128, 256)}
-CONV_KERNEL = "conv_mfma_kernel<2, 2, 9"
+# and 256 -> 256 @64x128 = conv_mfma_kernel<2, 1, 9, 2, ...> (in-workgroup K split), 64 tiles x 8 x 512 threads
+CONV_LAUNCHES = [("conv_mfma_kernel<2, 2, 9", 128 * 4 * 256, (1, 128, 128, 128, 256)),
+                 ("conv_mfma_kernel<2, 1, 9, 2", 64 * 8 * 512, (1, 256, 256, 64, 128))]
 
 
 def avg(dirname, counter, match="dcn_fwd"):
@@ -54,9 +55,9 @@ print(json.dumps(out))
 
 # ---- the same two passes reduced for the MFMA convolution (wide coalesced streams: the doubling applies) ----
 if len(sys.argv) > 4:
-    fetch, write = avg(sys.argv[1], "FETCH_SIZE", CONV_KERNEL), avg(sys.argv[2], "WRITE_SIZE", CONV_KERNEL)
     layers, raw = {}, {}
-    for grid, shape in CONV_SHAPES.items():
+    for kern, grid, shape in CONV_LAUNCHES:
+        fetch, write = avg(sys.argv[1], "FETCH_SIZE", kern), avg(sys.argv[2], "WRITE_SIZE", kern)
         if grid in fetch and grid in write:
             f, n = fetch[grid]
             w, _ = write[grid]

@@ -16,6 +16,6 @@ python3 tools/pmc_bench_traffic.py $out/FETCH_SIZE $out/WRITE_SIZE $out/dcn_fwd_
 for c in FETCH_SIZE WRITE_SIZE; do
   f=$(find $out/$c -name "*counter_collection.csv" | head -1)
   (head -1 $f; grep dcn_fwd $f) > $out/${tag}_bench_dcn_fwd_pmc_$c.csv
-  (head -1 $f; grep "conv_mfma_kernel<2, 2, 9" $f) > $out/${tag}_bench_conv_mfma_pmc_$c.csv
+  (head -1 $f; grep -e "conv_mfma_kernel<2, 2, 9" -e "conv_mfma_kernel<2, 1, 9, 2" $f) > $out/${tag}_bench_conv_mfma_pmc_$c.csv
   (head -1 $f; grep "conv_heads_fused" $f) > $out/${tag}_bench_heads_fused_pmc_$c.csv
 done
