@@ -162,6 +162,8 @@ __global__ __launch_bounds__(256 * KS, KS > 1 ? 4 : 2) void conv_mfma_kernel(CvA
   // the ncot workgroups that stage the SAME input tile (one per output-channel tile) would fetch it through 4 different
   // L2s -- 4.2x the input's bytes on the fabric side at 128 -> 128 (PMC FETCH_SIZE).  Workgroup w takes the logical index
   // (w % 8) * (n / 8) + w / 8: logical neighbours share an XCD, and with it the tile's rows in L2.
+  // (Channel-tile-major order for the deep, small maps whose weights outweigh their input -- 512 -> 512 @32x64 -- was
+  //  measured too: no gain.)
   int lw = blockIdx.x;
   if ((gridDim.x & 7) == 0) lw = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
   const int cot = lw % a.ncot, tile = lw / a.ncot;

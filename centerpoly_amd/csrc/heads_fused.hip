@@ -68,7 +68,10 @@ __global__ __launch_bounds__(256, 2) void conv_heads_fused_kernel(HeadsArgs a) {
   __shared__ bf16x8 Xs[2 * PLANE];
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, g = lane >> 4, c = lane & 15;
-  const int head = blockIdx.x % a.nheads, tile = blockIdx.x / a.nheads;
+  // (XCD-aware order, as in conv_mfma.hip: logical neighbours -- the heads of one tile, then the next tile -- share an L2)
+  int lw = blockIdx.x;
+  if ((gridDim.x & 7) == 0) lw = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  const int head = lw % a.nheads, tile = lw / a.nheads;
   const int x0 = (tile % a.tiles_x) * TW, y0 = (tile / a.tiles_x) * TH, b = blockIdx.y;
   const int HW = a.H * a.W;
   const int ncl = a.HC / 64, KS2 = a.HC / 32;
@@ -244,7 +247,12 @@ __global__ __launch_bounds__(512, 2) void conv_heads_fused_res_kernel(HeadsArgs 
   const int tid = threadIdx.x, lane = tid & 63, wid = (tid >> 6) & 3, g = lane >> 4, c = lane & 15;
   const int hsel = __builtin_amdgcn_readfirstlane(tid >> 8);
   const int npair = (a.nheads + 1) / 2;
-  const int head = 2 * (blockIdx.x % npair) + hsel, tile = blockIdx.x / npair;
+  // XCD-aware order: consecutive workgroups go round-robin over the 8 XCDs, so the head pairs of one tile (and the
+  // tiles sharing its halo rows) fetched the input through different L2s -- 114 MB on the fabric side for a 34 MB input
+  // (PMC FETCH_SIZE).  Workgroup w takes the logical index (w % 8) * (n / 8) + w / 8: logical neighbours share an XCD.
+  int lw = blockIdx.x;
+  if ((gridDim.x & 7) == 0) lw = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  const int head = 2 * (lw % npair) + hsel, tile = lw / npair;
   const int x0 = (tile % a.tiles_x) * TW, y0 = (tile / a.tiles_x) * TH, b = blockIdx.y;
   const int HW = a.H * a.W;
   const int ncl = a.HC / 64, KS2 = a.HC / 32;
