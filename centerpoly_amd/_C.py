@@ -39,6 +39,7 @@ class NativeError(RuntimeError):
 
 _lib = None
 
+ABI_VERSION = 2              # CP_ABI_VERSION of include/centerpoly_hip.h this binding was written against
 _P = c_void_p
 _SIGNATURES = {
     "cp_abi_version": (c_int32, []),
@@ -139,7 +140,7 @@ def lib():
             fn = getattr(l, name)
             fn.restype = res
             fn.argtypes = args
-        if l.cp_abi_version() != 2:
+        if l.cp_abi_version() != ABI_VERSION:
             raise NativeError("ABI version mismatch")
         _lib = l
     return _lib

@@ -32,6 +32,19 @@ def test_library_exports_every_declared_symbol():
     assert L.cp_strerror(-2) == b"unsupported shape or option"
 
 
+def test_graft_entry_build_and_header_version_agree():
+    """__graft_entry__.build() (the driver's "does it build" check) runs here, and the binding's ABI_VERSION is the
+    header's CP_ABI_VERSION (round 3 bumped it to 2: build() must follow)."""
+    import os, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import __graft_entry__
+    __graft_entry__.build()
+    with open(os.path.join(root, "include", "centerpoly_hip.h")) as fh:
+        m = re.search(r"#define\s+CP_ABI_VERSION\s+(\d+)", fh.read())
+    assert m and int(m.group(1)) == _C.ABI_VERSION == _C.lib().cp_abi_version()
+
+
 def test_argument_validation_without_gpu():
     """Entry points validate before touching the device: callable with no GPU."""
     L = _C.lib()
