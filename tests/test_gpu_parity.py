@@ -1279,3 +1279,32 @@ def test_maxpool2x2_forward_backward_match_torch(shape):
     xr = x.detach().clone().requires_grad_(True)
     (gr,) = torch.autograd.grad(F.max_pool2d(xr, 2, 2), xr, go)
     assert torch.equal(gx, gr)
+
+
+def test_zero_pool_hands_out_disjoint_zeroed_tensors():
+    """_C.zeros (the pooled accumulators the weight-gradient kernels add into): every tensor is zero, 256-byte aligned
+    and disjoint from every other live one; a used-up block is replaced, never re-zeroed under live tensors; large
+    requests bypass the pool."""
+    from centerpoly_amd import _C
+    pool = _C._zero_pool
+    taken, spans = [], []
+    n_blocks = 0
+    last_block = None
+    for i in range(60):
+        shape = (256, 64, 3, 3) if i % 3 == 0 else ((512,) if i % 3 == 1 else (1024, 1024))      # 0.6 MB, 2 KB, 4 MB
+        t = _C.zeros(shape, DEV)
+        assert t.is_contiguous() and t.dtype == torch.float32 and tuple(t.shape) == shape and t.data_ptr() % 256 == 0
+        assert not t.any()
+        t.fill_(float(i + 1))                              # what a kernel accumulating into it would do
+        taken.append(t)
+        spans.append((t.data_ptr(), t.data_ptr() + t.numel() * 4))
+        if pool.block is not last_block:
+            n_blocks += 1
+            last_block = pool.block
+    assert n_blocks >= 2                                   # 60 x ~1.5 MB crossed the 64 MB block at least once
+    spans.sort()
+    assert all(a[1] <= b[0] for a, b in zip(spans, spans[1:]))
+    for i, t in enumerate(taken):
+        assert (t == float(i + 1)).all()                   # nothing was re-zeroed or overwritten behind a live tensor
+    big = _C.zeros((4096, 4096), DEV)                      # 64 MB: not carved from a block
+    assert not big.any() and big.untyped_storage().nbytes() == 4096 * 4096 * 4
