@@ -1,4 +1,7 @@
 // What v_permlane16_swap_b32 does (gfx950): prints the two result registers for x = lane, y = 100 + lane.
+// Measured: r[0] = [x.row0, y.row0, x.row2, y.row2], r[1] = [x.row1, y.row1, x.row3, y.row3] (rows of 16 lanes): the odd rows
+// of the first operand trade places with the even rows of the second (used by conv_mfma.hip's epilogue).
+// Build: hipcc -O3 --offload-arch=gfx950 permlane16_swap.hip -o permlane16_swap
 #include <hip/hip_runtime.h>
 #include <cstdio>
 __global__ void k(unsigned* o) {
