@@ -413,7 +413,7 @@ def mfma_enabled():
     return _ENABLED
 
 
-def grads(x, weight, go, want_x=True, want_w=True, min_k=1):
+def grads(x, weight, go, want_x=True, want_w=True, min_k=1, residual=None):
     """(grad_x, grad_weight) of a stride-1 3x3 / pad 1 or 1x1 convolution from grad_out: the MFMA kernels where
     they take the shape (the input gradient contracts over Cout: below `min_k` output channels it goes to the
     library)."""
@@ -422,11 +422,14 @@ def grads(x, weight, go, want_x=True, want_w=True, min_k=1):
     taps, pad = weight.shape[2] * weight.shape[3], weight.shape[2] // 2
     B, _, H, W = x.shape
     gx = gw = None
-    if want_x:
-        if cout >= min_k and L.cp_conv3x3_mfma_supported(cout, cin, H, W):
-            gx = _launch(go, _prepare(weight, cout, cin, True), None, None, cin, False, taps)
+    if want_x:                                          # (+ residual: a gradient of the same input to accumulate onto)
+        if cout >= min_k and L.cp_conv3x3_mfma_supported(cout, cin, H, W) \
+                and (residual is None or residual.is_contiguous()):
+            gx = _launch(go, _prepare(weight, cout, cin, True), None, residual, cin, False, taps)
         else:
             gx = torch.nn.grad.conv2d_input(x.shape, weight, go, padding=pad)
+            if residual is not None:
+                gx = gx + residual
     if want_w:
         if _WGRAD and L.cp_conv3x3_mfma_wgrad_supported(cin, cout, H, W):
             gw = _C.zeros(weight.shape, weight.device)
@@ -484,59 +487,89 @@ def conv_bias_act(conv, x, relu):
     return _ConvBiasActFn.apply(x.contiguous(), conv.weight, conv.bias, bool(relu))
 
 
-class _HeadFn(torch.autograd.Function):
-    """A detection head in training -- Conv2d(3x3, bias) -> ReLU -> Conv2d(1x1, bias)
-    (src/lib/models/networks/pose_dla_dcn.py:445-462) -- as ONE autograd node: both forwards with their epilogues in
-    the kernels; backward: the 1x1 convolution's input gradient leaves the kernel already masked by the ReLU with the
-    3x3 bias gradient summed in its epilogue (cp_conv_mfma_input_grad_relu) -- no separate pass over the
-    [B][head_conv][H][W] map (4 x 537 MB at the training size)."""
+class _HeadsFn(torch.autograd.Function):
+    """The detection heads in training -- each Conv2d(3x3, bias) -> ReLU -> Conv2d(1x1, bias) on the SAME feature map
+    (src/lib/models/networks/pose_dla_dcn.py:445-462, 480-483) -- as ONE autograd node: both forwards of every head with
+    their epilogues in the kernels; backward per head: the 1x1 convolution's input gradient leaves the kernel already
+    masked by the ReLU with the 3x3 bias gradient summed in its epilogue (cp_conv_mfma_input_grad_relu) -- no separate
+    pass over the [B][head_conv][H][W] map (4 x 537 MB at the training size) -- and the heads' gradients of the shared
+    input are accumulated by the input-gradient launches themselves (`residual` operand) instead of three passes of
+    autograd's accumulation over the 134 MB map.  Arguments: x, then (w1, b1, w2, b2) per head; one output per head."""
 
     @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2):
-        c1, cin, c2 = w1.shape[0], w1.shape[1], w2.shape[0]
-        y = _launch(x, _prepare(w1, cin, c1, False), b1, None, c1, True, 9)
-        out = _launch(y, _prepare(w2, c1, c2, False), b2, None, c2, False, 1)
-        ctx.save_for_backward(x, w1, w2, y)
-        return out
+    def forward(ctx, x, *params):
+        n = len(params) // 4
+        outs, saved = [], [x]
+        for h in range(n):
+            w1, b1, w2, b2 = params[4 * h:4 * h + 4]
+            c1, cin, c2 = w1.shape[0], w1.shape[1], w2.shape[0]
+            y = _launch(x, _prepare(w1, cin, c1, False), b1, None, c1, True, 9)
+            outs.append(_launch(y, _prepare(w2, c1, c2, False), b2, None, c2, False, 1))
+            saved += [w1, w2, y]
+        ctx.save_for_backward(*saved)
+        return tuple(outs)
 
     @staticmethod
-    def backward(ctx, go):
-        x, w1, w2, y = ctx.saved_tensors
-        go = go.contiguous()
-        B, c2, H, W = go.shape
-        c1 = w1.shape[0]
+    def backward(ctx, *gos):
+        saved = ctx.saved_tensors
+        x = saved[0]
         L = _C.lib()
-        gb2 = _C.zeros((c2,), go.device)
-        _C.check(L.cp_channel_sum_accumulate(_C.ptr(go), _C.ptr(gb2), B, c2, H * W, _C.stream()), "cp_channel_sum_accumulate")
-        _, gw2 = grads(y, w2, go, False, ctx.needs_input_grad[3])
-        g = torch.empty_like(y)
-        gb1 = _C.zeros((c1,), go.device)
-        end = _C.kernel_timer.start(("conv1x1_igrad_relu", c2, c1, H, W, B)) if _C.kernel_timer is not None else None
-        ws = _C.workspace(L.cp_conv_mfma_input_grad_relu_workspace_bytes(B, c1, H, W), go.device)
-        _C.check(L.cp_conv_mfma_input_grad_relu(_C.ptr(go), _C.ptr(_prepare(w2, c2, c1, True)), _C.ptr(y), _C.ptr(g),
-                                                _C.ptr(gb1), B, c1, H, W, c2, 1, _C.ptr(ws), ws.numel(), _C.stream()),
-                 "cp_conv_mfma_input_grad_relu")
-        if end is not None:
-            end.record()
-        gx, gw1 = grads(x, w1, g, ctx.needs_input_grad[0], ctx.needs_input_grad[1], min_k=MIN_CIN)
-        return gx, gw1, gb1, gw2, gb2
+        gx, gparams = None, []
+        for h, go in enumerate(gos):
+            w1, w2, y = saved[1 + 3 * h:4 + 3 * h]
+            if go is None:                              # this head's output was not used
+                gparams += [None, None, None, None]
+                continue
+            go = go.contiguous()
+            B, c2, H, W = go.shape
+            c1 = w1.shape[0]
+            need = ctx.needs_input_grad[1 + 4 * h:5 + 4 * h]
+            gb2 = _C.zeros((c2,), go.device)
+            _C.check(L.cp_channel_sum_accumulate(_C.ptr(go), _C.ptr(gb2), B, c2, H * W, _C.stream()), "cp_channel_sum_accumulate")
+            _, gw2 = grads(y, w2, go, False, need[2])
+            g = torch.empty_like(y)
+            gb1 = _C.zeros((c1,), go.device)
+            end = _C.kernel_timer.start(("conv1x1_igrad_relu", c2, c1, H, W, B)) if _C.kernel_timer is not None else None
+            ws = _C.workspace(L.cp_conv_mfma_input_grad_relu_workspace_bytes(B, c1, H, W), go.device)
+            _C.check(L.cp_conv_mfma_input_grad_relu(_C.ptr(go), _C.ptr(_prepare(w2, c2, c1, True)), _C.ptr(y), _C.ptr(g),
+                                                    _C.ptr(gb1), B, c1, H, W, c2, 1, _C.ptr(ws), ws.numel(), _C.stream()),
+                     "cp_conv_mfma_input_grad_relu")
+            if end is not None:
+                end.record()
+            gxh, gw1 = grads(x, w1, g, ctx.needs_input_grad[0], need[0], min_k=MIN_CIN, residual=gx)
+            gx = gxh if gxh is not None else gx
+            gparams += [gw1, gb1, gw2, gb2]
+        return (gx,) + tuple(gparams)
 
 
-def head_train(fc, x):
-    """fc(x) for a head Sequential(Conv2d(3x3, bias), ReLU, Conv2d(1x1, bias)) in training as one autograd node
-    (_HeadFn); None when a shape is not the MFMA kernel's (the caller composes the head from its pieces)."""
+def _head_ok(fc, x):
     c0, c2 = fc[0], fc[2]
     if not (c0.bias is not None and c2.bias is not None and c0.kernel_size == (3, 3) and c2.kernel_size == (1, 1)
             and c0.stride == (1, 1) and c2.stride == (1, 1) and usable(c0, x)):
-        return None
+        return False
     B, _, H, W = x.shape
     L = _C.lib()
     c1, co = c0.out_channels, c2.out_channels
-    if not (c2.padding == (0, 0) and c2.dilation == (1, 1) and c2.groups == 1 and c1 >= MIN_CIN
-            and L.cp_conv3x3_mfma_supported(c1, co, H, W) and L.cp_conv3x3_mfma_supported(co, c1, H, W)
-            and _fills(B, c1, co, H, W) and (H * W) % 4 == 0 and B * max(c1, co) <= 65535):
+    return bool(c2.padding == (0, 0) and c2.dilation == (1, 1) and c2.groups == 1 and c1 >= MIN_CIN
+                and L.cp_conv3x3_mfma_supported(c1, co, H, W) and L.cp_conv3x3_mfma_supported(co, c1, H, W)
+                and _fills(B, c1, co, H, W) and (H * W) % 4 == 0 and B * max(c1, co) <= 65535)
+
+
+def heads_train(fcs, x):
+    """[fc(x) for fc in fcs] for heads Sequential(Conv2d(3x3, bias), ReLU, Conv2d(1x1, bias)) over one feature map in
+    training as ONE autograd node (_HeadsFn); None when a shape is not the MFMA kernel's."""
+    if not fcs or not all(_head_ok(fc, x) for fc in fcs):
         return None
-    return _HeadFn.apply(x.contiguous(), c0.weight, c0.bias, c2.weight, c2.bias)
+    params = []
+    for fc in fcs:
+        params += [fc[0].weight, fc[0].bias, fc[2].weight, fc[2].bias]
+    return list(_HeadsFn.apply(x.contiguous(), *params))
+
+
+def head_train(fc, x):
+    """fc(x) for one head (see heads_train); None when a shape is not the MFMA kernel's."""
+    out = heads_train([fc], x)
+    return None if out is None else out[0]
 
 
 def conv_raw(conv, x):

@@ -801,12 +801,11 @@ class DLASeg(nn.Module):
         if self.training and y[-1].is_cuda and all(
                 isinstance(getattr(self, h), nn.Sequential) and len(getattr(self, h)) == 3 for h in self.heads):
             # training: each head's Conv3x3 + bias + ReLU with the fused epilogue, then its 1x1 conv
-            out = {}
-            for h in self.heads:
-                fc = getattr(self, h)
-                o = conv3x3.head_train(fc, y[-1]) if torch.is_grad_enabled() and y[-1].dtype == torch.float32 else None
-                out[h] = o if o is not None else conv_bias(fc[2], conv_bias_relu(fc[0], y[-1]))
-            return [out]
+            fcs = [getattr(self, h) for h in self.heads]
+            outs = conv3x3.heads_train(fcs, y[-1]) if torch.is_grad_enabled() and y[-1].dtype == torch.float32 else None
+            if outs is None:                       # (shapes outside the MFMA kernels': the heads from their pieces)
+                outs = [conv_bias(fc[2], conv_bias_relu(fc[0], y[-1])) for fc in fcs]
+            return [dict(zip(self.heads, outs))]
         return [{head: getattr(self, head)(y[-1]) for head in self.heads}]
 
 

@@ -387,6 +387,42 @@ def test_training_head_single_node(cfg):
         assert torch.isfinite(a).all() and _rel(a, b) <= 1e-4, name
 
 
+def test_training_heads_share_one_node():
+    """conv3x3.heads_train: the four polydet heads over one feature map as ONE autograd node -- the shared input's gradient
+    is accumulated by the heads' input-gradient launches; all outputs and the input gradient against float64 torch (the
+    ReLU masks taken from the kernel's own hidden maps, as above), also with one head's output unused."""
+    from centerpoly_amd.models.networks import conv3x3
+    B, cin, hc, H, W = 2, 64, 128, 64, 136
+    couts = (8, 32, 1, 2)
+    fcs = []
+    for i, co in enumerate(couts):
+        fc = torch.nn.Sequential(torch.nn.Conv2d(cin, hc, 3, padding=1), torch.nn.ReLU(), torch.nn.Conv2d(hc, co, 1)).to(DEV)
+        with torch.no_grad():
+            fc[0].weight.copy_(_t("mh1%d" % i, (hc, cin, 3, 3), 0.05)); fc[0].bias.copy_(_t("mhb1%d" % i, (hc,), 0.3))
+            fc[2].weight.copy_(_t("mh2%d" % i, (co, hc, 1, 1), 0.1)); fc[2].bias.copy_(_t("mhb2%d" % i, (co,)))
+        fcs.append(fc)
+    x = _t("mhx", (B, cin, H, W)).requires_grad_(True)
+    outs = conv3x3.heads_train(fcs, x)
+    assert outs is not None and len(outs) == 4
+    gos = [_t("mhgo%d" % i, tuple(o.shape)) for i, o in enumerate(outs)]
+    xd = x.detach().double().requires_grad_(True)
+    refs = []
+    for fc in fcs:
+        with torch.no_grad():
+            keep = (conv3x3.conv_bias_act(fc[0], x.detach(), True) > 0).double()
+        refs.append(F.conv2d(F.conv2d(xd, fc[0].weight.detach().double(), fc[0].bias.detach().double(), padding=1) * keep,
+                             fc[2].weight.detach().double(), fc[2].bias.detach().double()))
+    for used in ((0, 1, 2, 3), (0, 2, 3)):
+        (gx,) = torch.autograd.grad([outs[i] for i in used], [x], [gos[i] for i in used], retain_graph=True)
+        (gxd,) = torch.autograd.grad([refs[i] for i in used], [xd], [gos[i].double() for i in used], retain_graph=True)
+        assert _rel(gx, gxd) <= 1e-4, used
+    for o, r in zip(outs, refs):
+        assert _rel(o, r.detach()) <= TOL
+    gw = torch.autograd.grad(outs, [fc[0].weight for fc in fcs], gos, retain_graph=True)
+    gwd = torch.autograd.grad(refs, [xd], [g.double() for g in gos])          # (keeps the float64 graph alive until here)
+    assert all(torch.isfinite(g).all() for g in gw) and torch.isfinite(gwd[0]).all()
+
+
 def test_skip_gradient_joins_in_the_input_gradient_launch():
     """conv3x3.conv_raw_skip: (conv(x), x) as one autograd node whose backward adds the skip's gradient in the
     input-gradient kernel's epilogue; against float64 torch, with and without a gradient on the skip."""
