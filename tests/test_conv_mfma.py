@@ -355,7 +355,7 @@ def test_stride_2_input_gradient(shape):
     assert _rel(g2, ref + res.double()) <= TOL
 
 
-@pytest.mark.parametrize("cfg", [(2, 64, 256, 8, 64, 136), (1, 64, 128, 32, 64, 128), (4, 48, 64, 1, 36, 132), (4, 64, 256, 2, 32, 64)],
+@pytest.mark.parametrize("cfg", [(2, 64, 256, 8, 64, 136), (2, 64, 128, 32, 64, 136), (4, 48, 64, 1, 36, 132), (4, 64, 256, 2, 32, 64)],
                          ids=["hm (8)", "poly (32)", "pseudo_depth (1), ragged map", "reg (2)"])
 def test_training_head_single_node(cfg):
     """conv3x3.head_train: Conv2d(3x3, bias) -> ReLU -> Conv2d(1x1, bias) as one autograd node whose backward masks the
