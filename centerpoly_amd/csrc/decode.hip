@@ -245,7 +245,14 @@ __global__ __launch_bounds__(S2_THREADS) void select_decode_kernel(DecodeArgs a)
     __syncthreads();
     prefix = (prefix << 8) | (unsigned long long)sel[0];
     need = sel[1];
+    const uint32_t in_bin = hist[sel[0]];                 // keys that carry the prefix so far
     __syncthreads();
+    // the four value passes are done and EVERY key with the K-th value is wanted (no tie straddles the cut, the
+    // normal case for float scores): the index passes would only reproduce the all-zero suffix
+    if (pass == 3 && in_bin == need) {
+      prefix <<= 32;
+      break;
+    }
   }
   const unsigned long long kth = prefix;
 #pragma unroll
