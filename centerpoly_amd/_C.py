@@ -86,10 +86,10 @@ _SIGNATURES = {
     "cp_conv_mfma_prepare": (c_int32, [_P, c_int32, c_int32, c_int32, c_int32, _P, _P]),
     "cp_conv3x3_s2_wgrad_supported": (c_int32, [c_int32] * 4),
     "cp_conv3x3_s2_wgrad": (c_int32, [_P, _P, _P] + [c_int32] * 5 + [_P]),
-    "cp_conv7x7s2_c3_supported": (c_int32, [c_int32] * 3),
-    "cp_conv7x7s2_c3_weight_bytes": (c_size_t, [c_int32]),
-    "cp_conv7x7s2_c3_prepare": (c_int32, [_P, c_int32, _P, _P]),
-    "cp_conv7x7s2_c3_forward": (c_int32, [_P, _P, _P, _P] + [c_int32] * 5 + [_P]),
+    "cp_conv7x7_c3_supported": (c_int32, [c_int32] * 4),
+    "cp_conv7x7_c3_weight_bytes": (c_size_t, [c_int32]),
+    "cp_conv7x7_c3_prepare": (c_int32, [_P, c_int32, _P, _P]),
+    "cp_conv7x7_c3_forward": (c_int32, [_P, _P, _P, _P] + [c_int32] * 6 + [_P]),
     "cp_conv_mfma_prepare_blocks": (c_int32, [c_int32] * 3),
     "cp_conv_mfma_prepare_batch": (c_int32, [_P, c_int32, c_int32, _P]),
     "cp_conv_mfma_forward": (c_int32, [_P, _P, c_int32, _P, _P, _P, _P] + [c_int32] * 6 + [_P]),

@@ -232,27 +232,28 @@ def s2_input_grad(xshape, weight, go):
 
 
 def stem_infer(x, conv, w, bias, relu):
-    """Inference: the Hourglass' 7x7 / stride 2 / pad 3 stem over a 3-channel image (cp_conv7x7s2_c3_forward) with the
-    (folded) weight `w`, + bias + ReLU in the epilogue; the permuted weights are cached on `conv` for as long as `w` is
-    the same, unmodified tensor.  None when the module is not that convolution."""
+    """Inference: a 7x7 / pad 3 convolution of a 3-channel image, stride 1 (DLA's base_layer) or 2 (the Hourglass stem),
+    on the bf16 matrix cores (cp_conv7x7_c3_forward) with the (folded) weight `w`, + bias + ReLU in the epilogue; the
+    permuted weights are cached on `conv` for as long as `w` is the same, unmodified tensor.  None when the module is
+    not that convolution (or the arithmetic is exact_f32)."""
     if not (_ENABLED and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and conv.kernel_size == (7, 7)
-            and conv.stride == (2, 2) and conv.padding == (3, 3) and conv.dilation == (1, 1) and conv.groups == 1
+            and conv.stride in ((1, 1), (2, 2)) and conv.padding == (3, 3) and conv.dilation == (1, 1) and conv.groups == 1
             and conv.in_channels == 3 and x.shape[1] == 3 and conv.padding_mode == "zeros"):
         return None
     L = _C.lib()
     B, _, H, W = x.shape
-    cout = w.shape[0]
-    if not L.cp_conv7x7s2_c3_supported(cout, H, W) or B > 65535:
+    cout, stride = w.shape[0], conv.stride[0]
+    if not L.cp_conv7x7_c3_supported(cout, H, W, stride) or B > 65535:
         return None
     cache = conv.__dict__.get("_stem_wperm")
     if cache is None or cache[0] is not w or cache[1] != w._version:
-        wp = torch.empty(L.cp_conv7x7s2_c3_weight_bytes(cout), dtype=torch.uint8, device=w.device)
-        _C.check(L.cp_conv7x7s2_c3_prepare(_C.ptr(w.contiguous()), cout, _C.ptr(wp), _C.stream()), "cp_conv7x7s2_c3_prepare")
+        wp = torch.empty(L.cp_conv7x7_c3_weight_bytes(cout), dtype=torch.uint8, device=w.device)
+        _C.check(L.cp_conv7x7_c3_prepare(_C.ptr(w.contiguous()), cout, _C.ptr(wp), _C.stream()), "cp_conv7x7_c3_prepare")
         cache = (w, w._version, wp)
         conv.__dict__["_stem_wperm"] = cache
-    out = torch.empty((B, cout, (H - 1) // 2 + 1, (W - 1) // 2 + 1), dtype=torch.float32, device=x.device)
-    _C.check(L.cp_conv7x7s2_c3_forward(_C.ptr(x.contiguous()), _C.ptr(cache[2]), _C.ptr(bias), _C.ptr(out), B, H, W, cout,
-                                       1 if relu else 0, _C.stream()), "cp_conv7x7s2_c3_forward")
+    out = torch.empty((B, cout, (H - 1) // stride + 1, (W - 1) // stride + 1), dtype=torch.float32, device=x.device)
+    _C.check(L.cp_conv7x7_c3_forward(_C.ptr(x.contiguous()), _C.ptr(cache[2]), _C.ptr(bias), _C.ptr(out), B, H, W, cout,
+                                     stride, 1 if relu else 0, _C.stream()), "cp_conv7x7_c3_forward")
     return out
 
 

@@ -147,13 +147,15 @@ def conv_train(conv, x):
 def _conv_folded(x, conv, wb, relu=False, residual=None):
     """conv with folded-BN weights, then ONE fused in-place pass: + bias (+ residual) (+ ReLU)."""
     if residual is None:
-        y = _conv_direct(x, conv, wb, relu)
+        y = None
+        if conv.kernel_size == (7, 7) and x.is_cuda:       # 3-channel 7x7: the bf16 matrix-core kernel (split_bf16 arithmetic)
+            y = conv3x3.stem_infer(x, conv, wb[0], wb[1], relu)
+        if y is None:
+            y = _conv_direct(x, conv, wb, relu)
         if y is not None:
             return y
     if x.is_cuda:
         y = conv3x3_infer(x, conv, wb[0], wb[1], residual, relu, conv=conv)
-        if y is None and residual is None:
-            y = conv3x3.stem_infer(x, conv, wb[0], wb[1], relu)      # the Hourglass' 7x7 / stride 2 stem
         if y is not None:
             return y
     if not x.is_cuda:

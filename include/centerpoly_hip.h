@@ -270,16 +270,17 @@ int cp_conv3x3_s2_wgrad_supported(int32_t Cin, int32_t Cout, int32_t H, int32_t 
 int cp_conv3x3_s2_wgrad(const float* x, const float* grad_out, float* gw, int32_t B, int32_t Cin, int32_t H, int32_t W,
                         int32_t Cout, void* stream);
 
-/* The Hourglass stem: 7x7 / stride 2 / pad 3 convolution of a 3-channel image (+ bias, + ReLU) on the bf16 matrix cores
- * (split-bf16 x3, the arithmetic above) -- `pre = convolution(7, 3, 128, stride=2)`,
- * src/lib/models/networks/large_hourglass.py:287-290 (cuDNN in the reference; BatchNorm folded by the caller):
- *   out[b][co][y][x] = act(bias[co] + sum w[co][ci][ky][kx] * x[b][ci][2 y - 3 + ky][2 x - 3 + kx])
- * x [B][3][H][W], weight [Cout][3][7][7] (prepared once into wperm), out [B][Cout][(H - 1) / 2 + 1][(W - 1) / 2 + 1]. */
-int cp_conv7x7s2_c3_supported(int32_t Cout, int32_t H, int32_t W);
-size_t cp_conv7x7s2_c3_weight_bytes(int32_t Cout);
-int cp_conv7x7s2_c3_prepare(const float* weight, int32_t Cout, void* wperm, void* stream);
-int cp_conv7x7s2_c3_forward(const float* x, const void* wperm, const float* bias, float* out, int32_t B, int32_t H,
-                            int32_t W, int32_t Cout, int32_t relu, void* stream);
+/* 7x7 / pad 3 convolution of a 3-channel image (+ bias, + ReLU), stride 1 or 2, on the bf16 matrix cores (split-bf16 x3,
+ * the arithmetic above): the Hourglass stem `pre = convolution(7, 3, 128, stride=2)`
+ * (src/lib/models/networks/large_hourglass.py:287-290) and DLA's `base_layer` Conv2d(3, 16, 7, stride=1)
+ * (src/lib/models/networks/pose_dla_dcn.py:236-241); cuDNN in the reference, BatchNorm folded by the caller:
+ *   out[b][co][y][x] = act(bias[co] + sum w[co][ci][ky][kx] * x[b][ci][S y - 3 + ky][S x - 3 + kx])
+ * x [B][3][H][W], weight [Cout][3][7][7] (prepared once into wperm), out [B][Cout][(H - 1) / S + 1][(W - 1) / S + 1]. */
+int cp_conv7x7_c3_supported(int32_t Cout, int32_t H, int32_t W, int32_t stride);
+size_t cp_conv7x7_c3_weight_bytes(int32_t Cout);
+int cp_conv7x7_c3_prepare(const float* weight, int32_t Cout, void* wperm, void* stream);
+int cp_conv7x7_c3_forward(const float* x, const void* wperm, const float* bias, float* out, int32_t B, int32_t H,
+                          int32_t W, int32_t Cout, int32_t stride, int32_t relu, void* stream);
 
 /* Input gradient of a stride-1 convolution (3x3 / pad 1 or 1x1) whose INPUT was the output y of a bias + ReLU epilogue
  * (the heads' Conv2d(3x3, bias) -> ReLU -> Conv2d(1x1), src/lib/models/networks/pose_dla_dcn.py:445-462), with that

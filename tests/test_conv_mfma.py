@@ -499,21 +499,24 @@ def test_weight_bank_serves_only_current_versions():
     assert len(conv3x3._BANK.entries) == n
 
 
-@pytest.mark.parametrize("cfg", [(2, 128, 64, 96), (1, 128, 37, 70), (1, 96, 130, 258), (3, 64, 9, 33)],
-                         ids=["128 ch", "ragged map", "96 channels, off the tile grid", "tiny"])
+@pytest.mark.parametrize("cfg", [(2, 128, 64, 96, 2), (1, 128, 37, 70, 2), (1, 96, 130, 258, 2), (3, 64, 9, 33, 2),
+                                 (2, 16, 64, 96, 1), (1, 16, 37, 70, 1), (1, 16, 130, 258, 1), (1, 24, 9, 33, 1), (2, 16, 41, 67, 2)],
+                         ids=["128 ch", "ragged map", "96 channels, off the tile grid", "tiny", "base layer (16, stride 1)",
+                              "base layer, ragged map", "base layer, off the tile grid", "24 channels stride 1", "16 channels stride 2"])
 def test_hourglass_stem_kernel(cfg):
-    """cp_conv7x7s2_c3_forward: 7x7 / stride 2 / pad 3 over a 3-channel image (+ bias + ReLU) against float64 torch."""
-    B, co, H, W = cfg
+    """cp_conv7x7_c3_forward: 7x7 / pad 3 over a 3-channel image (+ bias + ReLU), stride 2 (Hourglass stem) and stride 1
+    (DLA base layer), against float64 torch."""
+    B, co, H, W, S = cfg
     L = _C.lib()
     x, w, bias = _t("stx%s" % (cfg,), (B, 3, H, W)), _t("stw%s" % (cfg,), (co, 3, 7, 7), 0.1), _t("stb%s" % (cfg,), (co,))
-    assert L.cp_conv7x7s2_c3_supported(co, H, W)
-    wp = torch.empty(L.cp_conv7x7s2_c3_weight_bytes(co), dtype=torch.uint8, device=DEV)
-    _C.check(L.cp_conv7x7s2_c3_prepare(P(w), co, P(wp), _C.stream()), "prepare")
-    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    assert L.cp_conv7x7_c3_supported(co, H, W, S)
+    wp = torch.empty(L.cp_conv7x7_c3_weight_bytes(co), dtype=torch.uint8, device=DEV)
+    _C.check(L.cp_conv7x7_c3_prepare(P(w), co, P(wp), _C.stream()), "prepare")
+    Ho, Wo = (H - 1) // S + 1, (W - 1) // S + 1
     for relu in (1, 0):
         out = torch.full((B, co, Ho, Wo), float("nan"), device=DEV)
-        _C.check(L.cp_conv7x7s2_c3_forward(P(x), P(wp), P(bias), P(out), B, H, W, co, relu, _C.stream()), "stem")
-        ref = F.conv2d(x.double(), w.double(), bias.double(), stride=2, padding=3)
+        _C.check(L.cp_conv7x7_c3_forward(P(x), P(wp), P(bias), P(out), B, H, W, co, S, relu, _C.stream()), "stem")
+        ref = F.conv2d(x.double(), w.double(), bias.double(), stride=S, padding=3)
         ref = F.relu(ref) if relu else ref
         assert tuple(ref.shape) == tuple(out.shape)
         assert torch.isfinite(out).all() and _rel(out, ref) <= TOL
