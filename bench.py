@@ -5,10 +5,12 @@
                    NMS/top-k/decode (BASELINE config 2); `value` = inference img/s.  The same
                    line carries the 1-GPU training point (`train`, with the DCNv2 backward
                    rooflines), the DCNv2 forward roofline measured with HIP events inside the timed
-                   region (`roofline` against the fp32 matrix pipe that bounds it, `roofline_hbm`
-                   for the same launch against HBM), the same launch on other offset fields
-                   (`roofline_by_offsets`), BASELINE configs 4 and 5 (`other_configs`) and the CPU
-                   oracle timed on a bounded sample (`cpu_baseline`).
+                   region (`roofline`: algorithmic bytes against HBM, the north star's figure;
+                   `roofline_mfma`: the same launch's algorithmic flops against the matrix pipe), the
+                   same launch on other offset fields (`roofline_by_offsets`), BASELINE configs 4 and
+                   5 (`other_configs`) and the CPU oracle timed on a bounded sample (`cpu_baseline`).
+                   stdout carries ONE compact line (< 8 KB: `compact_line`); the full tables go to
+                   stderr and gpurun_out/bench_detail.json (`write_detail`).
   N > 1            one step = one data-parallel training step (BASELINE config 3: DLA-34 + DCNv2,
                    4 images of 2048x1024 per GPU, 16-vertex cartesian head, l1+iou polygon loss,
                    Adam): forward, losses, backward with bucketed RCCL all-reduce, optimizer.
@@ -145,7 +147,7 @@ def note(msg):
         print("[bench %s] %s" % (time.strftime("%H:%M:%S"), msg), file=sys.stderr, flush=True)
 
 
-def build_model(dev, train, dcn_contraction="auto", arch="dla_34", heads=None, offset_weight_scale=0.5):
+def build_model(dev, train, dcn_contraction="auto", arch="dla_34", heads=None, offset_weight_scale=1.0):
     import torch
     from centerpoly_amd import synth
     from centerpoly_amd.models.model import create_model
@@ -303,12 +305,12 @@ def dcn_roofline(summary, tag="dcn_fwd", fwd_contraction="auto"):
 
 def split_bf16_roofline(common, alg_flops, avg_s):
     """Matrix-pipe roofline of a kernel that forms every fp32 product from three bf16 MFMA products
-    (hi*hi + hi*lo + lo*hi): the flops it ISSUES are 3x the algorithmic ones and are priced against
-    the dense bf16 peak; the fp32-equivalent rate is reported beside it."""
+    (hi*hi + hi*lo + lo*hi).  `achieved` / `frac` are the ALGORITHMIC flops over the launch time against
+    the dense bf16 peak; the flops the kernel ISSUES are 3x those and are reported apart as `issued_frac`."""
     issued = 3.0 * alg_flops
-    return dict(common, bound="mfma", achieved=issued / avg_s / 1e12, peak=MFMA_BF16_PEAK_TF, unit="TFLOP/s",
-                frac=issued / avg_s / 1e12 / MFMA_BF16_PEAK_TF, algorithmic_flops_per_launch=alg_flops,
-                issued_bf16_flops_per_launch=issued, fp32_equivalent_tflops=alg_flops / avg_s / 1e12,
+    return dict(common, bound="mfma", achieved=alg_flops / avg_s / 1e12, peak=MFMA_BF16_PEAK_TF, unit="TFLOP/s",
+                frac=alg_flops / avg_s / 1e12 / MFMA_BF16_PEAK_TF, algorithmic_flops_per_launch=alg_flops,
+                issued_bf16_flops_per_launch=issued, issued_frac=issued / avg_s / 1e12 / MFMA_BF16_PEAK_TF,
                 arithmetic="split-bf16 x3 on v_mfma_f32_16x16x32_bf16, fp32 accumulate")
 
 
@@ -403,7 +405,7 @@ def golden_error(dev):
 
 # --------------------------------------------------------------------- legs ---
 def infer_leg(args, dev, world, arch="dla_34", heads=None, rep="cartesian", steps=None, warmup=None,
-              offset_weight_scale=0.5, tag="infer"):
+              offset_weight_scale=1.0, tag="infer"):
     import torch
     from centerpoly_amd import _C, synth
     from centerpoly_amd.models.decode import polydet_decode
@@ -559,8 +561,8 @@ def train_rooflines(summary):
         from centerpoly_amd.models.networks.DCNv2.dcn_v2 import DCN
         hbm, mfma = dcn_roofline(summary, tag, DCN.train_contraction)
         if mfma is not None:
-            out[name] = mfma
-            out[name + "_hbm"] = hbm
+            out[name] = hbm                    # DCNv2: the north star's HBM fraction is the headline of the pair
+            out[name + "_mfma"] = mfma
     for tag, name in (("conv3x3_fwd", "roofline_conv3x3"), ("conv3x3_wgrad", "roofline_conv3x3_wgrad")):
         hbm, mfma = conv_roofline(summary, tag)
         if mfma is not None:
@@ -697,6 +699,88 @@ def other_config_points(args, dev):
         out["config5"] = {"error": "%s: %s" % (type(e).__name__, e)}
     return out
 
+# --------------------------------------------------------------- the JSON line ---
+LINE_LIMIT = 8000      # bytes; the driver keeps the tail of stdout, a 21 KB line lost its head in round 3
+
+
+def _sig(v, n=5):
+    """Floats to n significant digits (recursively); everything else unchanged."""
+    if isinstance(v, float):
+        return float("%.*g" % (n, v))
+    if isinstance(v, dict):
+        return {k: _sig(x, n) for k, x in v.items()}
+    if isinstance(v, (list, tuple)):
+        return [_sig(x, n) for x in v]
+    return v
+
+
+def _pick(d, keys):
+    return None if d is None else {k: d[k] for k in keys if k in d}
+
+
+ROOF_KEYS = ("kernel", "bound", "avg_launch_us", "launches", "algorithmic_bytes_per_launch",
+             "algorithmic_flops_per_launch", "achieved", "peak", "unit", "frac", "issued_frac", "traffic")
+
+
+def write_detail(line, args):
+    """Everything the compact line leaves out (per-family tables, the other configs' rooflines, sources of the PMC
+    traffic figures ...) goes to stderr and to a side file; returns the file's path relative to the repo."""
+    text = json.dumps(_sig(line, 7), indent=1, sort_keys=True)
+    print("[bench detail]\n" + text, file=sys.stderr, flush=True)
+    for rel in (os.path.join("gpurun_out", "bench_detail.json"), "bench_detail.json"):
+        try:
+            os.makedirs(os.path.dirname(os.path.join(ROOT, rel)) or ROOT, exist_ok=True)
+            with open(os.path.join(ROOT, rel), "w") as fh:
+                fh.write(text + "\n")
+            return rel
+        except OSError:
+            continue
+    return "stderr only"
+
+
+def compact_line(line):
+    """The ONE stdout line: the contract's keys, the rooflines as algorithmic fractions, the precision contract, the
+    training point and the CPU baseline -- below LINE_LIMIT bytes whatever the legs produced."""
+    out = {k: line[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                "scaling", "vs_baseline", "dtype", "data", "config") if k in line}
+    for k in ("roofline", "roofline_mfma", "roofline_bwd_data", "roofline_bwd_data_mfma", "roofline_bwd_weight",
+              "roofline_bwd_weight_mfma", "roofline_conv3x3", "roofline_heads"):
+        if line.get(k) is not None:
+            out[k] = _pick(line[k], ROOF_KEYS)
+    if "max_rel_err_vs_golden" in line:
+        out["max_rel_err_vs_golden"] = {k: v for k, v in line["max_rel_err_vs_golden"].items() if k != "reference"}
+    for k in ("exact_f32", "split_bf16"):
+        if k in line:
+            out[k] = _pick(line[k], ("value", "ms_per_step", "steps", "warmup"))
+    if "roofline_by_offsets" in line:
+        out["roofline_by_offsets"] = [{"offsets": p["offsets"].split(" (")[0], "avg_launch_us": p["avg_launch_us"],
+                                       "hbm_frac": p["hbm_frac"]} for p in line["roofline_by_offsets"]["points"]]
+    if "detector_end_to_end" in line:
+        out["detector_end_to_end"] = _pick(line["detector_end_to_end"], ("value", "ms_per_image"))
+    if "train" in line:
+        tr = line["train"]
+        out["train"] = _pick(tr, ("metric", "value", "ms_per_step", "n_gpus", "global_batch", "steps", "warmup"))
+        for k in ("roofline", "roofline_bwd_data", "roofline_bwd_weight"):
+            if tr.get(k) is not None:
+                out["train"][k] = _pick(tr[k], ROOF_KEYS)
+        if "dcn_ms_per_step" in tr:
+            out["train"]["family_ms_per_step"] = tr["dcn_ms_per_step"]
+    if "other_configs" in line:
+        out["other_configs"] = {c: _pick(v, ("metric", "value", "ms_per_step", "steps", "warmup", "n_gpus", "error"))
+                                for c, v in line["other_configs"].items()}
+    for k in ("scaling_base", "cpu_baseline", "detail"):
+        if k in line:
+            out[k] = line[k]
+    out = _sig(out)
+    text = json.dumps(out, separators=(",", ":"))
+    for drop in ("other_configs", "roofline_by_offsets", "roofline_heads", "roofline_conv3x3", "detector_end_to_end"):
+        if len(text) <= LINE_LIMIT:
+            break
+        out.pop(drop, None)                      # never reached with today's legs; the limit is a hard promise
+        text = json.dumps(out, separators=(",", ":"))
+    assert len(text) <= LINE_LIMIT, len(text)
+    return text
+
 
 def main(argv=None):
     argv = sys.argv[1:] if argv is None else argv
@@ -761,10 +845,10 @@ def main(argv=None):
             "value": world * args.steps / t, "ms_per_step": 1e3 * t / args.steps,
             "config": {"workload": workload, "images_per_step": world,
                        "parallelism": "replicas" if world > 1 else "single"},
-            # the dominant kernel's arithmetic intensity (119 FLOP/B) is 6x the fp32 ridge point
-            # (157.3 TFLOP/s / 8 TB/s = 19.7 FLOP/B): the fp32 matrix pipe is the binding roofline,
-            # the HBM fraction of the same launch is reported beside it
-            "roofline": mfma, "roofline_hbm": hbm,
+            # `roofline` is the north star's figure -- the dominant DCNv2 forward launch against HBM (algorithmic
+            # bytes of SURVEY 8(d) / HIP-event launch time / 8 TB/s); `roofline_mfma` prices the same launch's
+            # algorithmic flops against the matrix pipe it issues on (the issued flops are `issued_frac`)
+            "roofline": hbm, "roofline_mfma": mfma,
             "roofline_conv3x3": cmfma, "roofline_conv3x3_hbm": chbm,
             "roofline_heads": hmfma, "roofline_heads_hbm": hhbm,
             "dcn_layers_ms": {"%d->%d@%dx%d" % k[1:5]: round(v["avg_ms"], 4) for k, v in summary.items()
@@ -781,12 +865,6 @@ def main(argv=None):
         if world == 1 and cfg == "2":
             if not args.no_offset_points:
                 line["roofline_by_offsets"] = offset_field_points(dev, infer_contraction(args))
-                t1, s1 = infer_leg(args, dev, 1, steps=10, warmup=2, offset_weight_scale=1.0, tag="infer(unscaled)")
-                _, m1 = dcn_roofline(s1, fwd_contraction=infer_contraction(args))
-                line["infer_unscaled_offset_weights"] = {
-                    "what": "the same step with conv_offset_mask weights at their full fan-in scale (offsets "
-                            "twice as large as in `value`'s model)",
-                    "value": 10 / t1, "ms_per_step": 1e3 * t1 / 10, "steps": 10, "roofline": m1}
                 note("offset-field points done")
             if not args.no_exact_point:
                 # the precision contract beside the headline: error of the timed arithmetic against the reference's
@@ -837,7 +915,8 @@ def main(argv=None):
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args)
-        print(json.dumps(line), flush=True)
+        line["detail"] = write_detail(line, args)
+        print(compact_line(line), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

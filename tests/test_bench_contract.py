@@ -95,3 +95,43 @@ def test_traffic_is_null_for_a_stale_kernel_revision(tmp_path, monkeypatch):
         {"kernel_rev": "abc", "inputs": "bench.py infer leg", "layers": {"1x64x64x256x512": 5.0}}))
     assert bench.measured_traffic(64, 64, 256, 512, 1)[0] == 5.0
     assert bench.measured_traffic(64, 64, 256, 512, 4)[0] is None
+
+
+def test_compact_line_fits_the_driver_capture():
+    """Round 3's 21 KB stdout line lost its head in the driver's capture (BENCH_r03: parsed = null).  The line is now
+    built by `compact_line` from the full record: every contract key, algorithmic roofline fractions, < 8 KB even when
+    every leg ran and every string is long."""
+    bench = _bench()
+    import json
+    full = json.load(open(os.path.join(ROOT, "profiles", "r03_bench_n1.json")))     # a full record of every leg
+    full["roofline_mfma"] = full["roofline"]
+    full["roofline"] = full.pop("roofline_hbm")
+    for k in ("roofline", "roofline_bwd_data", "roofline_bwd_weight"):
+        full["train"][k + "_mfma"] = full["train"][k]
+        full["train"][k] = full["train"].pop(k + "_hbm")
+    full["detail"] = "gpurun_out/bench_detail.json"
+    text = bench.compact_line(full)
+    assert len(text) < bench.LINE_LIMIT <= 8000 and "\n" not in text
+    line = json.loads(text)
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "roofline_mfma", "cpu_baseline", "train",
+                "exact_f32", "max_rel_err_vs_golden"):
+        assert key in line, key
+    r = line["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["algorithmic_bytes_per_launch"] / (r["avg_launch_us"] * 1e-6) / 8e12) < 1e-3 * r["frac"]
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 * r["frac"]
+    assert set(line["cpu_baseline"]) >= {"value", "unit", "cores", "kind", "sample"}
+    assert "model" not in line["config"] and "workload" in line["config"]
+    # a pathological record (every string 2 KB long) still fits: optional blocks are dropped, never the contract keys
+    fat = json.loads(json.dumps(full))
+    fat["other_configs"] = {"config%d" % i: {"metric": "m" * 2000, "value": 1.0} for i in range(4, 9)}
+    text = bench.compact_line(fat)
+    assert len(text) <= bench.LINE_LIMIT and "roofline" in json.loads(text) and "cpu_baseline" in json.loads(text)
+
+
+def test_split_bf16_roofline_prices_algorithmic_flops():
+    bench = _bench()
+    r = bench.split_bf16_roofline({}, 9.66e9, 50e-6)
+    assert abs(r["frac"] - 9.66e9 / 50e-6 / 2.5e15) < 1e-9
+    assert abs(r["issued_frac"] - 3 * r["frac"]) < 1e-12
