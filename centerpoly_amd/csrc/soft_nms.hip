@@ -2,7 +2,7 @@
 //
 // Replaces the Cython extension external.nms.soft_nms the detector calls when several test
 // scales are merged or --nms is set (reference: src/lib/external/nms.pyx:77-170, call site
-// src/lib/detectors/polydet.py:66-67).  Literal behaviour, `cdef float` arithmetic: only
+// src/lib/detectors/polydet.py:66-67).  Literal behaviour, the arithmetic of the Cython-generated C: only
 // columns 0-4 of a row are swapped / overwritten, discarded rows are overwritten by the last
 // live row and the array keeps its length; the return value is the live count N.
 #include <math.h>
@@ -33,15 +33,18 @@ extern "C" int cp_soft_nms(float* boxes, int32_t n, int32_t row_stride, float si
     int pos = i + 1;
     while (pos < N) {
       const float x1 = at(pos, 0), y1 = at(pos, 1), x2 = at(pos, 2), y2 = at(pos, 3);
-      const float area = (x2 - x1 + 1) * (y2 - y1 + 1);
-      const float iw = fminf(tx2, x2) - fmaxf(tx1, x1) + 1;
+      // Cython writes the int literal of `x2 - x1 + 1` as the double constant 1.0: float difference, then double
+      // (pinned by the reference's own build, tests/golden/softnms_ref.npz)
+      const float area = (float)(((double)(x2 - x1) + 1.0) * ((double)(y2 - y1) + 1.0));
+      const float iw = (float)((double)((tx2 <= x2 ? tx2 : x2) - (tx1 >= x1 ? tx1 : x1)) + 1.0);
       if (iw > 0) {
-        const float ih = fminf(ty2, y2) - fmaxf(ty1, y1) + 1;
+        const float ih = (float)((double)((ty2 <= y2 ? ty2 : y2) - (ty1 >= y1 ? ty1 : y1)) + 1.0);
         if (ih > 0) {
-          const float ua = (tx2 - tx1 + 1) * (ty2 - ty1 + 1) + area - iw * ih;
-          const float ov = iw * ih / ua;
+          const float ua = (float)(((double)(tx2 - tx1) + 1.0) * ((double)(ty2 - ty1) + 1.0) + (double)area -
+                                   (double)(iw * ih));
+          const float ov = (iw * ih) / ua;
           float weight;
-          if (method == 1) weight = ov > Nt ? 1 - ov : 1;
+          if (method == 1) weight = ov > Nt ? (float)(1.0 - (double)ov) : 1.f;
           else if (method == 2) weight = (float)exp((double)(-(ov * ov) / sigma));
           else weight = ov > Nt ? 0.f : 1.f;
           at(pos, 4) = weight * at(pos, 4);

@@ -6,10 +6,11 @@ affine_transform) and src/lib/detectors/polydet.py:45-76.
 `cv2.getAffineTransform` (image.py:56,58) is the exact affine through three
 point pairs; restated as a 6x6 linear solve in float64.
 
-soft_nms follows src/lib/external/nms.pyx:77-170 (Cython, `cdef float` arithmetic emulated
-with numpy float32 scalars).  PARITY OF soft_nms IS UNPINNED: the reference's nms.pyx does not
-compile against this image's numpy 2.2 / Cython 3.2 (`np.int_t`, `np.float` no longer exist),
-so it could not be built into oracle/_ref, and the reference holds no fixture for it.
+soft_nms follows src/lib/external/nms.pyx:77-170 (Cython).  PINNED since round 4: oracle/build_ref_nms.py compiles
+the reference's file into oracle/_ref/ (two tokens of the unrelated `nms()` patched in memory for numpy 2, `soft_nms`
+itself unmodified), tests/golden/gen_softnms_golden.py records its outputs, tests/test_detector_io.py holds this
+restatement and the C ABI to them bit for bit.  (The pin corrected the round-1 restatement: Cython turns the int
+literal in `x2 - x1 + 1` into the double constant 1.0, so those sums run in double -- 1-ulp differences in the scores.)
 """
 import numpy as np
 
@@ -100,9 +101,14 @@ def soft_nms(boxes, sigma=0.5, Nt=0.3, threshold=0.001, method=0):
     """external/nms.pyx:77-170, IN PLACE on float32 [n, >= 5] rows (x1,y1,x2,y2,score,...).
     Literal behaviour: only columns 0-4 are swapped / overwritten (the polygon columns of a
     row stay where they were), rows are never removed from the array (N shrinks internally),
-    and the caller in detectors/polydet.py:66-67 ignores the returned keep list."""
-    f = np.float32
-    one = f(1)
+    and the caller in detectors/polydet.py:66-67 ignores the returned keep list.
+
+    Arithmetic = what Cython makes of the `cdef float` text (pinned bit for bit by tests/golden/softnms_ref.npz, the
+    reference's own build): an int literal next to a C float becomes the DOUBLE constant `1.0`, so `x2 - x1 + 1` is a
+    float difference plus 1.0 in double; `area`, `iw`, `ih` round to float on assignment; `ua = float(...)` is a
+    double expression rounded to float; `ov`, `-(ov*ov)/sigma` and `weight*score` are float operations; `1 - ov` is
+    double rounded to float; `np.exp` runs in double on the float quotient."""
+    f, d = np.float32, np.float64
     sigma, Nt, threshold = f(sigma), f(Nt), f(threshold)
     N0 = N = boxes.shape[0]
     for i in range(N0):                      # range(N) is evaluated once (i is a Python object)
@@ -119,19 +125,19 @@ def soft_nms(boxes, sigma=0.5, Nt=0.3, threshold=0.001, method=0):
         pos = i + 1
         while pos < N:
             x1, y1, x2, y2 = boxes[pos, 0], boxes[pos, 1], boxes[pos, 2], boxes[pos, 3]
-            area = (x2 - x1 + one) * (y2 - y1 + one)
-            iw = min(tx2, x2) - max(tx1, x1) + one
+            area = f((d(x2 - x1) + 1.0) * (d(y2 - y1) + 1.0))
+            iw = f(d((tx2 if tx2 <= x2 else x2) - (tx1 if tx1 >= x1 else x1)) + 1.0)
             if iw > 0:
-                ih = min(ty2, y2) - max(ty1, y1) + one
+                ih = f(d((ty2 if ty2 <= y2 else y2) - (ty1 if ty1 >= y1 else y1)) + 1.0)
                 if ih > 0:
-                    ua = (tx2 - tx1 + one) * (ty2 - ty1 + one) + area - iw * ih
-                    ov = iw * ih / ua
+                    ua = f((d(tx2 - tx1) + 1.0) * (d(ty2 - ty1) + 1.0) + d(area) - d(iw * ih))
+                    ov = (iw * ih) / ua
                     if method == 1:
-                        weight = one - ov if ov > Nt else one
+                        weight = f(1.0 - d(ov)) if ov > Nt else f(1)
                     elif method == 2:
-                        weight = f(np.exp(np.float64(-(ov * ov) / sigma)))
+                        weight = f(np.exp(d(-(ov * ov) / sigma)))
                     else:
-                        weight = f(0) if ov > Nt else one
+                        weight = f(0) if ov > Nt else f(1)
                     boxes[pos, 4] = weight * boxes[pos, 4]
                     if boxes[pos, 4] < threshold:
                         boxes[pos, 0:5] = boxes[N - 1, 0:5]

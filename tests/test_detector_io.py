@@ -175,6 +175,38 @@ def test_soft_nms_c_matches_oracle_bitwise(method, n, spread):
     assert np.array_equal(a, b)
 
 
+def _softnms_fixture():
+    import os
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "softnms_ref.npz"))
+    for i in range(int(d["n_cases"])):
+        sigma, Nt, thr, method = d["c%d_par" % i]
+        yield i, d["c%d_in" % i], d["c%d_out" % i], d["c%d_keep" % i].tolist(), float(sigma), float(Nt), float(thr), int(method)
+
+
+def test_soft_nms_oracle_matches_the_reference_build_bitwise():
+    """tests/golden/softnms_ref.npz holds the outputs of the reference's OWN Cython soft_nms (src/lib/external/nms.pyx:77-170,
+    compiled by oracle/build_ref_nms.py, generated by tests/golden/gen_softnms_golden.py): the restatement in
+    oracle/post.py reproduces every table bit for bit and every keep list -- row f4 is pinned."""
+    n = 0
+    for i, a, want, keep, sigma, Nt, thr, method in _softnms_fixture():
+        b = a.copy()
+        got_keep = opost.soft_nms(b, sigma=sigma, Nt=Nt, threshold=thr, method=method)
+        assert got_keep == keep, i
+        assert np.array_equal(b.view(np.uint32), want.view(np.uint32)), i
+        n += 1
+    assert n == 18
+
+
+def test_soft_nms_c_abi_matches_the_reference_build_bitwise():
+    """cp_soft_nms (csrc/soft_nms.hip, host C++) against the same fixtures of the reference's own build."""
+    from centerpoly_amd.external.nms import soft_nms
+    for i, a, want, keep, sigma, Nt, thr, method in _softnms_fixture():
+        b = a.copy()
+        got_keep = soft_nms(b, sigma=sigma, Nt=Nt, threshold=thr, method=method)
+        assert got_keep == keep, i
+        assert np.array_equal(b.view(np.uint32), want.view(np.uint32)), i
+
+
 def test_soft_nms_known_answers():
     from centerpoly_amd.external.nms import soft_nms
     # two identical boxes: the second keeps exp(-1 / sigma) of its score (gaussian), polygon columns untouched
