@@ -39,7 +39,7 @@ class NativeError(RuntimeError):
 
 _lib = None
 
-ABI_VERSION = 2              # CP_ABI_VERSION of include/centerpoly_hip.h this binding was written against
+ABI_VERSION = 3              # CP_ABI_VERSION of include/centerpoly_hip.h this binding was written against
 _P = c_void_p
 _SIGNATURES = {
     "cp_abi_version": (c_int32, []),
@@ -74,6 +74,7 @@ _SIGNATURES = {
     "cp_polydet_post_process": (c_int32, [_P, _P, c_float, c_int32, c_int32, c_int32, _P, _P]),
     "cp_polydet_targets_workspace_bytes": (c_size_t, [POINTER(TargetShape)]),
     "cp_polydet_targets": (c_int32, [POINTER(TargetShape)] + [_P] * 19 + [_P, c_size_t, _P]),
+    "cp_polydet_dense_targets": (c_int32, [POINTER(TargetShape), _P, _P, c_size_t, _P, _P, _P]),
     "cp_conv_direct_supported": (c_int32, [c_int32] * 5),
     "cp_conv_direct_wgrad_supported": (c_int32, [c_int32] * 5),
     "cp_conv_direct_wgrad": (c_int32, [_P, _P, _P] + [c_int32] * 8 + [_P]),
@@ -109,6 +110,7 @@ _SIGNATURES = {
     "cp_soft_nms": (c_int32, [_P, c_int32, c_int32, c_float, c_float, c_float, c_int32]),
     "cp_polydet_decode_workspace_bytes": (c_size_t, [c_int32] * 5),
     "cp_polydet_decode": (c_int32, [_P, _P, _P, _P] + [c_int32] * 7 + [_P, _P, _P, _P, c_size_t, _P]),
+    "cp_polydet_decode_ex": (c_int32, [_P, _P, _P, _P] + [c_int32] * 8 + [_P, _P, _P, _P, c_size_t, _P]),
     "cp_sigmoid_focal_workspace_bytes": (c_size_t, [c_int64]),
     "cp_sigmoid_focal_forward": (c_int32, [_P, _P, c_int64, _P, _P, _P, c_size_t, _P]),
     "cp_sigmoid_focal_backward": (c_int32, [_P, _P, c_int64, _P, _P, _P, _P]),
@@ -117,6 +119,9 @@ _SIGNATURES = {
     "cp_mse_workspace_bytes": (c_size_t, []),
     "cp_mse_forward": (c_int32, [_P, _P, c_int64, _P, _P, c_size_t, _P]),
     "cp_mse_backward": (c_int32, [_P, _P, c_int64, _P, _P, _P]),
+    "cp_dense_l1_workspace_bytes": (c_size_t, []),
+    "cp_dense_l1_forward": (c_int32, [_P, _P, _P, c_int64, c_float, _P, _P, c_size_t, _P]),
+    "cp_dense_l1_backward": (c_int32, [_P, _P, _P, c_int64, _P, _P, _P, _P]),
     "cp_poly_iou_order_workspace_bytes": (c_size_t, [c_int32] * 3),
     "cp_poly_iou_order_forward": (c_int32, [_P, _P, _P, _P] + [c_int32] * 6 + [_P, _P, _P, _P,
                                                                                c_size_t, _P]),

@@ -45,6 +45,7 @@ struct W2Args {
   int pad, dil, mask_is_logit;
   int tpr, ntiles;            // tiles per row, tiles per image
   int T, runs_per_image;      // tiles per workgroup run
+  int chunks, slabs;          // input-channel chunks of 16, output-channel slabs of 64 (1-D grid: see the kernels)
 };
 
 template <int SLAB>             // output channels per workgroup (64; wider layers take several slabs in grid z)
@@ -61,9 +62,26 @@ __global__ __launch_bounds__(512, 4) void dcn_bwd_weight2_kernel(W2Args a) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lci = lane & 15, g = lane >> 4;
-  const int b = blockIdx.x / a.runs_per_image, run = blockIdx.x - b * a.runs_per_image;
-  const int c0 = blockIdx.y * KC;
-  const int co0 = blockIdx.z * SLAB;
+  // XCD-aware order (1-D grid): workgroups L and L + 8 share an XCD and its L2.  The Cin / 16 channel-chunk workgroups
+  // of one tile run all read the run's grad_out tiles and offsets: they take consecutive dispatch slots on ONE XCD
+  // (L = ((run group * nchunkslab + chunkslab) * 8 + run % 8), so three of their four fetches hit that L2 -- the y / z
+  // grid of round 3 dispatched a run's chunks 256 workgroups apart and fetched everything per chunk from memory.
+  int runb, cs;
+  {
+    const int L = blockIdx.x, nrb = a.runs_per_image * a.B, ncs = a.chunks * a.slabs;
+    if ((nrb & 7) == 0) {
+      const int q = L >> 3;
+      cs = q % ncs;
+      runb = (q / ncs) * 8 + (L & 7);
+    } else {
+      runb = L % nrb;
+      cs = L / nrb;
+    }
+  }
+  const int b = runb / a.runs_per_image, run = runb - b * a.runs_per_image;
+  const int chunk_i = cs % a.chunks;
+  const int c0 = chunk_i * KC;
+  const int co0 = (cs / a.chunks) * SLAB;
   const int HW = a.H * a.W;
   const float* xb = a.x + (long long)b * a.Cin * HW;
   const float* gob = a.go + (long long)b * a.Cout * HW;
@@ -121,7 +139,7 @@ __global__ __launch_bounds__(512, 4) void dcn_bwd_weight2_kernel(W2Args a) {
     }
   };
   float gbsum = 0.f;                                 // thread (co = tid >> 3, part = tid & 7): 16 pixels of a grad_out row
-  const bool do_bias = a.gb != nullptr && blockIdx.y == 0;
+  const bool do_bias = a.gb != nullptr && chunk_i == 0;
   if (t_begin < t_end) fetch(t_begin);
   for (int tile = t_begin; tile < t_end; ++tile) {
     int ty0, tx0;
@@ -338,9 +356,26 @@ __global__ __launch_bounds__(512, 4) void dcn_bwd_weight3_kernel(W2Args a) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lci = lane & 15, g = lane >> 4;
-  const int b = blockIdx.x / a.runs_per_image, run = blockIdx.x - b * a.runs_per_image;
-  const int c0 = blockIdx.y * KC;
-  const int co0 = blockIdx.z * SLAB;
+  // XCD-aware order (1-D grid): workgroups L and L + 8 share an XCD and its L2.  The Cin / 16 channel-chunk workgroups
+  // of one tile run all read the run's grad_out tiles and offsets: they take consecutive dispatch slots on ONE XCD
+  // (L = ((run group * nchunkslab + chunkslab) * 8 + run % 8), so three of their four fetches hit that L2 -- the y / z
+  // grid of round 3 dispatched a run's chunks 256 workgroups apart and fetched everything per chunk from memory.
+  int runb, cs;
+  {
+    const int L = blockIdx.x, nrb = a.runs_per_image * a.B, ncs = a.chunks * a.slabs;
+    if ((nrb & 7) == 0) {
+      const int q = L >> 3;
+      cs = q % ncs;
+      runb = (q / ncs) * 8 + (L & 7);
+    } else {
+      runb = L % nrb;
+      cs = L / nrb;
+    }
+  }
+  const int b = runb / a.runs_per_image, run = runb - b * a.runs_per_image;
+  const int chunk_i = cs % a.chunks;
+  const int c0 = chunk_i * KC;
+  const int co0 = (cs / a.chunks) * SLAB;
   const int HW = a.H * a.W;
   const float* xb = a.x + (long long)b * a.Cin * HW;
   const float* gob = a.go + (long long)b * a.Cout * HW;
@@ -397,7 +432,7 @@ __global__ __launch_bounds__(512, 4) void dcn_bwd_weight3_kernel(W2Args a) {
   float gbsum[NGO];                                  // grad_bias partial sums of this thread's NGO output channels
 #pragma unroll
   for (int i = 0; i < NGO; ++i) gbsum[i] = 0.f;
-  const bool do_bias = a.gb != nullptr && blockIdx.y == 0;
+  const bool do_bias = a.gb != nullptr && chunk_i == 0;
   const bool ci_ok = c0 + lci < a.Cin;
   const float* xc = xb + (long long)min(c0 + lci, a.Cin - 1) * HW;
 
@@ -617,7 +652,9 @@ int cp_dcn_bwd_weight2(const cp_dcn_shape* s, const float* x, const float* offse
   if (T > a.ntiles) T = a.ntiles;
   a.T = T;
   a.runs_per_image = (a.ntiles + T - 1) / T;
-  const dim3 grid(a.runs_per_image * s->B, chunks, slabs);
+  a.chunks = chunks;
+  a.slabs = slabs;
+  const dim3 grid(a.runs_per_image * s->B * chunks * slabs, 1, 1);
   // split-bf16 form by default (needs whole float4 groups of grad_out: W % 4 == 0); CP_DCN_BWD_EXACT_F32: exact f32
   const bool exact = (flags & CP_DCN_BWD_EXACT_F32) != 0;
   if (!exact && (s->W & 3) == 0)

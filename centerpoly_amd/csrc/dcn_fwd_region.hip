@@ -52,7 +52,8 @@ constexpr int ITEMS = CELLS * 4 / 256;    // float4 cells staged per thread and 
 #define CP_RABL 0
 #endif
 #ifndef CP_RPRIO
-#define CP_RPRIO 1      // per-chunk priority alternation between the workgroups sharing a CU (0: off, for A/B timing)
+#define CP_RPRIO 0      // per-chunk priority alternation between the workgroups sharing a CU: OFF since round 4 (A/B on the
+                        // final round-3 kernel: 50.7 us with, 50.8 without; libcp_rprio.so builds it with the alternation ON)
 #endif
 constexpr int RABL = CP_RABL;
 // diagnostic build (make libcp_rstamp.so, tools/probe_region_stamp.py): wave 0 of every workgroup overwrites 8 floats of
@@ -488,13 +489,16 @@ __global__ __launch_bounds__(256, 2) void dcn_fwd_region_kernel(RegionArgs a) {
   RSTAMP(3);
 
   const unsigned kgoff = (unsigned)kg * (2u * PLANE);
+#if CP_RPRIO
   const int prio_half = (int)((blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) >> 8);
+#endif
   for (int c = 0; c < nchunk; ++c) {
 #if CP_RPRIO
     // The two workgroups of a CU share its SIMDs; VALU issue goes to the older wave, so one of them finishes its K loop
     // ~25 % later than the other and the launch waits for it.  Alternating the priority per chunk between the halves of
     // the grid (workgroups b and b + 256 of the dispatch order are the ones that meet on a CU under round-robin
-    // placement; a wrong guess costs nothing) evens them out: 53.8 -> 49.8 us on the dominant launch.
+    // placement; a wrong guess costs nothing) evened them out on an early form of this kernel (53.8 -> 49.8 us); on the
+    // final kernel the A/B shows nothing (profiles/r03_dcn_fwd_region_ablations.txt), so it is compiled out by default.
     if (((prio_half) ^ c) & 1) __builtin_amdgcn_s_setprio(1);
     else __builtin_amdgcn_s_setprio(0);
 #endif

@@ -194,7 +194,7 @@ struct DecodeArgs {
   float* dets;
   long long* inds;
   int* clses;
-  int C, H, W, N2, K, rep, ncand;
+  int C, H, W, N2, K, rep, ncand, cat_spec;
 };
 
 template <int EPT>
@@ -281,12 +281,14 @@ __global__ __launch_bounds__(S2_THREADS) void select_decode_kernel(DecodeArgs a)
 
   // ---- decode the K winners ----
   const int K = a.K, N2 = a.N2, HW = a.H * a.W;
-  const float* pb = a.polys + (long long)b * N2 * HW;
+  // (--cat_spec_poly, decode.py:534-537: one polygon per class, the detection's class picks its channel block)
+  const float* pb = a.polys + (long long)b * N2 * (a.cat_spec ? a.C : 1) * HW;
   for (int q = tid; q < K * N2; q += S2_THREADS) {
     const int k = q / N2, j = q - k * N2;
     const uint32_t e = ~(uint32_t)(top[k] & 0xffffffffull);
     const int sp = (int)(e % (uint32_t)HW);
-    rows[q] = pb[(long long)j * HW + sp];
+    const int cbase = a.cat_spec ? (int)(e / (uint32_t)HW) * N2 : 0;
+    rows[q] = pb[(long long)(cbase + j) * HW + sp];
   }
   __syncthreads();
   if (a.rep != CP_REP_CARTESIAN) {
@@ -358,6 +360,15 @@ extern "C" int cp_polydet_decode(const float* heat, const float* polys, const fl
                                  int32_t N2, int32_t K, int32_t rep, float* dets, int64_t* inds,
                                  int32_t* clses, void* workspace, size_t workspace_bytes,
                                  void* stream) {
+  return cp_polydet_decode_ex(heat, polys, depth, reg, B, C, H, W, N2, K, rep, 0, dets, inds, clses, workspace,
+                              workspace_bytes, stream);
+}
+
+extern "C" int cp_polydet_decode_ex(const float* heat, const float* polys, const float* depth,
+                                    const float* reg, int32_t B, int32_t C, int32_t H, int32_t W,
+                                    int32_t N2, int32_t K, int32_t rep, int32_t cat_spec_poly, float* dets,
+                                    int64_t* inds, int32_t* clses, void* workspace, size_t workspace_bytes,
+                                    void* stream) {
   CP_CHECK_ARG(heat && polys && depth && dets && workspace);
   CP_CHECK_ARG(B > 0 && C > 0 && H > 0 && W > 0 && N2 > 0 && (N2 & 1) == 0 && K > 0);
   CP_CHECK_ARG(rep >= CP_REP_CARTESIAN && rep <= CP_REP_POLAR_FIXED);
@@ -378,6 +389,7 @@ extern "C" int cp_polydet_decode(const float* heat, const float* polys, const fl
   a.cand = cand; a.polys = polys; a.depth = depth; a.reg = reg; a.dets = dets;
   a.inds = (long long*)inds; a.clses = clses;
   a.C = C; a.H = H; a.W = W; a.N2 = N2; a.K = K; a.rep = rep; a.ncand = (int)ncand;
+  a.cat_spec = cat_spec_poly ? 1 : 0;
   const int ept = (int)((ncand + S2_THREADS - 1) / S2_THREADS);
   if (ept <= 4) hipLaunchKernelGGL(select_decode_kernel<4>, dim3(B), dim3(S2_THREADS), row_lds, st, a);
   else if (ept <= 16) hipLaunchKernelGGL(select_decode_kernel<16>, dim3(B), dim3(S2_THREADS), row_lds, st, a);

@@ -414,3 +414,92 @@ extern "C" int cp_mse_backward(const float* x, const float* gt, int64_t n, const
                      grad_loss, grad_x);
   return cp_launch_status();
 }
+
+
+// ------------------------------------------------------------------ dense masked L1 (--dense_poly) ---
+// trains/polydet.py:107-110: mask_weight = dense_poly_mask.sum() + 1e-4;
+//   poly_loss = L1Loss(reduction='sum')(output['poly'] * mask, dense_poly * mask) / mask_weight
+// One streaming pass each way over the [B, 2N, h, w] maps; double block partials (|diff| and mask), fixed-order final sum.
+namespace {
+__global__ __launch_bounds__(256) void dense_l1_fwd_kernel(const float* __restrict__ p, const float* __restrict__ t,
+                                                           const float* __restrict__ m, long long n,
+                                                           double* __restrict__ part) {
+  double s = 0.0, sm = 0.0;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const float mk = m[i];
+    s += (double)fabsf(p[i] * mk - t[i] * mk);          // (the reference multiplies both operands by the mask first)
+    sm += (double)mk;
+  }
+  s = cp_wave_sum_d(s);
+  sm = cp_wave_sum_d(sm);
+  __shared__ double red[8];
+  if ((threadIdx.x & 63) == 0) {
+    red[threadIdx.x >> 6] = s;
+    red[4 + (threadIdx.x >> 6)] = sm;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    part[2 * blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+    part[2 * blockIdx.x + 1] = red[4] + red[5] + red[6] + red[7];
+  }
+}
+
+__global__ __launch_bounds__(256) void dense_l1_final_kernel(const double* __restrict__ part, int nparts, float eps,
+                                                             float* __restrict__ out2) {
+  double s = 0.0, sm = 0.0;
+  for (int i = threadIdx.x; i < nparts; i += 256) {
+    s += part[2 * i];
+    sm += part[2 * i + 1];
+  }
+  s = cp_wave_sum_d(s);
+  sm = cp_wave_sum_d(sm);
+  __shared__ double red[8];
+  if ((threadIdx.x & 63) == 0) {
+    red[threadIdx.x >> 6] = s;
+    red[4 + (threadIdx.x >> 6)] = sm;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float den = (float)(red[4] + red[5] + red[6] + red[7]) + eps;     // float32 sum + 1e-4, as the tensor expression
+    out2[1] = den;
+    out2[0] = (float)(red[0] + red[1] + red[2] + red[3]) / den;
+  }
+}
+
+__global__ __launch_bounds__(256) void dense_l1_bwd_kernel(const float* __restrict__ p, const float* __restrict__ t,
+                                                           const float* __restrict__ m, long long n,
+                                                           const float* __restrict__ den,
+                                                           const float* __restrict__ grad_loss, float* __restrict__ g) {
+  const float sc = grad_loss[0] / den[0];
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const float mk = m[i];
+    const float d = p[i] * mk - t[i] * mk;
+    const float sg = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);                // torch's sign(0) = 0
+    g[i] = sg * mk * sc;
+  }
+}
+}  // namespace
+
+extern "C" size_t cp_dense_l1_workspace_bytes(void) { return 2 * MSE_BLOCKS * sizeof(double); }
+
+extern "C" int cp_dense_l1_forward(const float* pred, const float* target, const float* mask, int64_t n, float eps,
+                                   float* out2, void* workspace, size_t workspace_bytes, void* stream) {
+  CP_CHECK_ARG(pred && target && mask && out2 && n > 0 && workspace && workspace_bytes >= cp_dense_l1_workspace_bytes());
+  long long nb = (n + 255) / 256;
+  if (nb > MSE_BLOCKS) nb = MSE_BLOCKS;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(dense_l1_fwd_kernel, dim3((unsigned)nb), dim3(256), 0, st, pred, target, mask, (long long)n,
+                     (double*)workspace);
+  hipLaunchKernelGGL(dense_l1_final_kernel, dim3(1), dim3(256), 0, st, (const double*)workspace, (int)nb, eps, out2);
+  return cp_launch_status();
+}
+
+extern "C" int cp_dense_l1_backward(const float* pred, const float* target, const float* mask, int64_t n,
+                                    const float* den, const float* grad_loss, float* grad_pred, void* stream) {
+  CP_CHECK_ARG(pred && target && mask && den && grad_loss && grad_pred && n > 0);
+  long long nb = (n + 255) / 256;
+  if (nb > 4096) nb = 4096;
+  hipLaunchKernelGGL(dense_l1_bwd_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, pred, target, mask,
+                     (long long)n, den, grad_loss, grad_pred);
+  return cp_launch_status();
+}

@@ -247,7 +247,63 @@ __global__ __launch_bounds__(256) void targets_splat_kernel(TargetArgs a) {
   }
 }
 
+// --dense_poly (sample/polydet.py:401-403 -> utils/image.py:176-204 draw_dense_reg, called once per object right after
+// the object's splat): regmap[:, window] = poly[k] wherever gaussian_k >= hm.max(axis=0) AS IT STANDS after objects
+// 0..k.  One thread per pixel replays the objects in order with a running class-maximum: float64 Gaussian (the splat's
+// own expression) against the float32 map value -- so where object k itself sets the maximum the test is
+// g >= float32(g), true only when the rounding to float32 went down (the reference's behaviour, reproduced).
+__global__ __launch_bounds__(256) void targets_dense_kernel(const int* __restrict__ desc_all, const float* __restrict__ poly,
+                                                            float* __restrict__ dense, float* __restrict__ dmask, int M,
+                                                            int N, int h, int w) {
+  const int b = blockIdx.y;
+  const int px = blockIdx.x * 256 + threadIdx.x;
+  if (px >= h * w) return;
+  const int y = px / w, x = px - y * w;
+  const int ds = desc_stride(N);
+  float run_max = 0.f;
+  int cur = -1;
+  for (int k = 0; k < M; ++k) {
+    const int* desc = desc_all + ((long long)b * M + k) * ds;
+    const int radius = desc[0];
+    if (radius < 0) continue;
+    const int cx = desc[2], cy = desc[3];
+    const int left = min(cx, radius), right = min(w - cx, radius + 1);
+    const int top = min(cy, radius), bottom = min(h - cy, radius + 1);
+    if (left + right <= 0 || top + bottom <= 0 || cx - left < 0 || cy - top < 0) continue;
+    if (x < cx - left || x >= cx + right || y < cy - top || y >= cy + bottom) continue;
+    const double diameter = (double)(2 * radius + 1);
+    const double sigma = diameter / 6;
+    const double denom = 2 * sigma * sigma;
+    const double dx = (double)(x - cx), dy = (double)(y - cy);
+    double g = exp(-(dx * dx + dy * dy) / denom);
+    if (g < 2.220446049250313e-16) g = 0.0;
+    run_max = fmaxf(run_max, (float)g);                  // hm.max(axis=0) after draw_gaussian(hm[cls], ...)
+    if (g >= (double)run_max) cur = k;
+  }
+  const long long plane = (long long)h * w;
+  float* d = dense + (long long)b * 2 * N * plane + px;
+  float* m = dmask + (long long)b * 2 * N * plane + px;
+  const float* row = cur >= 0 ? poly + ((long long)b * M + cur) * 2 * N : nullptr;
+  for (int c = 0; c < 2 * N; ++c) {
+    const float v = row ? row[c] : 0.f;
+    d[c * plane] = v;
+    m[c * plane] = v != 0.f ? 1.f : 0.f;
+  }
+}
+
 }  // namespace
+
+extern "C" int cp_polydet_dense_targets(const cp_target_shape* s, const float* poly, const void* workspace,
+                                        size_t workspace_bytes, float* dense_poly, float* dense_mask, void* stream) {
+  CP_CHECK_ARG(s && poly && workspace && dense_poly && dense_mask);
+  CP_CHECK_ARG(s->B > 0 && s->max_objs > 0 && s->nbr_points >= 3 && s->out_h > 0 && s->out_w > 0);
+  if (s->B > 65535) return CP_EUNSUPPORTED;
+  if (workspace_bytes < cp_polydet_targets_workspace_bytes(s)) return CP_EWORKSPACE;
+  const int hw = s->out_h * s->out_w;
+  hipLaunchKernelGGL(targets_dense_kernel, dim3((hw + 255) / 256, s->B), dim3(256), 0, (hipStream_t)stream,
+                     (const int*)workspace, poly, dense_poly, dense_mask, s->max_objs, s->nbr_points, s->out_h, s->out_w);
+  return cp_launch_status();
+}
 
 extern "C" size_t cp_polydet_targets_workspace_bytes(const cp_target_shape* s) {
   if (!s || s->B <= 0 || s->max_objs <= 0 || s->nbr_points <= 0) return 0;

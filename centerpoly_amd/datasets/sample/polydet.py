@@ -43,9 +43,13 @@ def collate(packed):
 
 
 def build_targets(raw, output_h, output_w, num_classes, rep="cartesian", no_reorder_flip=False,
-                  with_border_hm=True):
+                  with_border_hm=True, dense_poly=False, cat_spec_poly=False):
     """raw: dict of DEVICE tensors with the keys of pack_annotations, batched on dim 0.
-    Returns the batch dict (device tensors) the polydet loss consumes."""
+    Returns the batch dict (device tensors) the polydet loss consumes.
+    dense_poly (`--dense_poly`, sample/polydet.py:401-403,429-441): adds 'dense_poly' / 'dense_poly_mask' [B,2N,h,w]
+    (cp_polydet_dense_targets) and drops 'poly', as the reference's dict does.  cat_spec_poly (:245-248,288-291,424-425):
+    adds 'cat_spec_poly' / 'cat_spec_mask' [B,M,C*2N] -- every object's polygon row in its class's block -- and drops
+    the keys the reference's cat-spec dict lacks (freq_mask, border_hm, wh)."""
     bbox = raw["bbox"]
     if not bbox.is_cuda:
         raise _C.NativeError("build_targets needs HIP device tensors (got %s); there is no CPU "
@@ -82,6 +86,26 @@ def build_targets(raw, output_h, output_w, num_classes, rep="cartesian", no_reor
         "cp_polydet_targets")
     if not with_border_hm:
         del out["border_hm"]
+    if cat_spec_poly:
+        # index bookkeeping on the device (no arithmetic): row k -> block cls_id[k] of a [C, 2N] table, for the slots
+        # the object kernel filled (h > 0 and w > 0: wh is set there and nowhere else)
+        L2 = 2 * N
+        live = (out["wh"][..., 0] > 0) & (out["wh"][..., 1] > 0)
+        cls = t["cls_id"].long().clamp(0, num_classes - 1)
+        onehot = torch.zeros((B, M, num_classes), dtype=torch.float32, device=dev)
+        onehot.scatter_(2, cls.unsqueeze(2), 1.0)
+        onehot = onehot * live.unsqueeze(2).float()
+        out["cat_spec_poly"] = (onehot.unsqueeze(3) * out["poly"].unsqueeze(2)).reshape(B, M, num_classes * L2)
+        out["cat_spec_mask"] = onehot.unsqueeze(3).expand(B, M, num_classes, L2).reshape(B, M, num_classes * L2).to(torch.uint8)
+        for k in ("freq_mask", "border_hm", "wh"):
+            out.pop(k, None)
+    if dense_poly:
+        dp = torch.empty((B, 2 * N, output_h, output_w), **f32)
+        dm = torch.empty((B, 2 * N, output_h, output_w), **f32)
+        _C.check(lib.cp_polydet_dense_targets(shape, _C.ptr(out["poly"]), _C.ptr(ws), nws, _C.ptr(dp), _C.ptr(dm),
+                                              _C.stream()), "cp_polydet_dense_targets")
+        out["dense_poly"], out["dense_poly_mask"] = dp, dm
+        del out["poly"]
     return out
 
 

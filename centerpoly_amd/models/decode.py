@@ -8,10 +8,10 @@ import torch
 from .. import _C
 
 
-def _decode_native(heat, polys, depth, reg, K, rep):
+def _decode_native(heat, polys, depth, reg, K, rep, cat_spec_poly=False):
     L = _C.lib()
     B, C, H, W = heat.shape
-    N2 = polys.shape[1]
+    N2 = polys.shape[1] // C if cat_spec_poly else polys.shape[1]
     heat, polys, depth = heat.contiguous(), polys.contiguous(), depth.contiguous()
     reg = reg.contiguous() if reg is not None else None
     for t in (heat, polys, depth) + ((reg,) if reg is not None else ()):
@@ -23,10 +23,10 @@ def _decode_native(heat, polys, depth, reg, K, rep):
     clses = torch.empty((B, K), dtype=torch.int32, device=dev)
     nb = L.cp_polydet_decode_workspace_bytes(B, C, H, W, K)
     ws = _C.workspace(nb, dev)
-    rc = L.cp_polydet_decode(_C.ptr(heat), _C.ptr(polys), _C.ptr(depth), _C.ptr(reg), B, C, H, W,
-                             N2, K, _C.REP[rep], _C.ptr(dets), _C.ptr(inds), _C.ptr(clses),
-                             _C.ptr(ws), ws.numel(), _C.stream())
-    _C.check(rc, "cp_polydet_decode")
+    rc = L.cp_polydet_decode_ex(_C.ptr(heat), _C.ptr(polys), _C.ptr(depth), _C.ptr(reg), B, C, H, W,
+                                N2, K, _C.REP[rep], 1 if cat_spec_poly else 0, _C.ptr(dets), _C.ptr(inds),
+                                _C.ptr(clses), _C.ptr(ws), ws.numel(), _C.stream())
+    _C.check(rc, "cp_polydet_decode_ex")
     return dets, inds, clses
 
 
@@ -35,8 +35,14 @@ def polydet_decode(heat, polys, depth, reg=None, cat_spec_poly=False, K=100, rep
     """decode.py:512-670.  heat is the ACTIVATED heat map [B,C,h,w]; returns
     dets[B,K,2N+7] = [x1,y1,x2,y2,score,cls,poly(2N),depth]."""
     if cat_spec_poly:
-        raise NotImplementedError("--cat_spec_poly is outside the accelerated path")
-    dets, inds, clses = _decode_native(heat, polys, depth, reg, K, rep)
+        # decode.py:514,534-535: `nbr_points = int(polys.shape[-1])` is read off the MAP (its width), and
+        # `polys.view(batch, K, cat, nbr_points)` then only succeeds when the head has cat * width channels; the
+        # reference raises torch's view error otherwise, and so does this mirror (same type, same message form).
+        B, cat, _, W = heat.shape
+        if polys.shape[1] != cat * W:
+            raise RuntimeError("shape '[%d, %d, %d, %d]' is invalid for input of size %d"
+                               % (B, K, cat, W, B * K * polys.shape[1]))
+    dets, inds, clses = _decode_native(heat, polys, depth, reg, K, rep, cat_spec_poly)
     if return_inds:
         return dets, inds, clses
     return dets

@@ -163,6 +163,37 @@ class MSELoss(nn.Module):
         return _Mse.apply(out, target)
 
 
+class _DenseL1(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, target, mask, eps):
+        L = _C.lib()
+        pred, target, mask = _f32c(pred), _f32c(target), _f32c(mask)
+        if pred.shape != target.shape or pred.shape != mask.shape:
+            raise _C.NativeError("dense L1: pred, target and mask must have one shape")
+        out2 = torch.empty((2,), dtype=torch.float32, device=pred.device)
+        nws = L.cp_dense_l1_workspace_bytes()
+        ws = _C.workspace(nws, pred.device)
+        _C.check(L.cp_dense_l1_forward(_C.ptr(pred), _C.ptr(target), _C.ptr(mask), pred.numel(), float(eps), _C.ptr(out2),
+                                       _C.ptr(ws), nws, _C.stream()), "cp_dense_l1_forward")
+        ctx.save_for_backward(pred, target, mask, out2)
+        return out2[0]
+
+    @staticmethod
+    def backward(ctx, grad_loss):
+        pred, target, mask, out2 = ctx.saved_tensors
+        g = torch.empty_like(pred)
+        _C.check(_C.lib().cp_dense_l1_backward(_C.ptr(pred), _C.ptr(target), _C.ptr(mask), pred.numel(),
+                                               _C.c_void_p(out2.data_ptr() + 4), _C.ptr(_f32c(grad_loss.reshape(1))),
+                                               _C.ptr(g), _C.stream()), "cp_dense_l1_backward")
+        return g, None, None, None
+
+
+def dense_poly_l1_loss(pred, target, mask, eps=1e-4):
+    """`--dense_poly` (trains/polydet.py:107-110): L1Loss(reduction='sum')(pred * mask, target * mask) /
+    (mask.sum() + 1e-4) over the whole [B, 2N, h, w] maps, one HIP streaming pass each way."""
+    return _DenseL1.apply(pred, target, mask, eps)
+
+
 # ------------------------------------------------------- polygon losses -----
 
 class _PolyIouOrder(torch.autograd.Function):

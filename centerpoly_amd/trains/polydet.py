@@ -2,18 +2,21 @@
 
 Aggregation, weights, returned stats keys and the in-place activation of
 output['hm'] follow the reference; every term is a HIP kernel and stays a device
-scalar.  Switches outside the accelerated path (mse_loss, eval_oracle_*,
-cat_spec_poly, dense_poly; reference :49-70,103-111, all default off) raise.
+scalar.  `--dense_poly` (:107-110) is a dense masked-L1 kernel; `--cat_spec_poly` (:103-106) hands PolyLoss a
+[B, M, C*2N] mask whose rows `if mask[batch][i]:` cannot reduce to a bool -- the reference raises RuntimeError on the first
+object (models/losses.py:870) and so does this mirror.  The `--eval_oracle_*` switches (:49-70, numba BFS maps of an
+evaluation-protocol experiment, all default off) raise NotImplementedError.
 """
 import torch
 
 from ..models.decode import polydet_decode
-from ..models.losses import FocalLoss, MSELoss, PolyLoss, RegL1Loss, RegLoss, sigmoid_focal_loss
+from ..models.losses import (FocalLoss, MSELoss, PolyLoss, RegL1Loss, RegLoss, dense_poly_l1_loss,
+                             sigmoid_focal_loss)
 from ..utils.post_process import polydet_post_process
 from .base_trainer import BaseTrainer
 
 _UNSUPPORTED = ("eval_oracle_hm", "eval_oracle_border_hm", "eval_oracle_offset",
-                "eval_oracle_poly", "eval_oracle_pseudo_depth", "cat_spec_poly", "dense_poly")
+                "eval_oracle_poly", "eval_oracle_pseudo_depth")
 
 
 class PolydetLoss(torch.nn.Module):
@@ -43,14 +46,26 @@ class PolydetLoss(torch.nn.Module):
             else:                            # _sigmoid + FocalLoss fused; output['hm'] becomes the activated map
                 hm_l, output["hm"] = sigmoid_focal_loss(output["hm"], batch["hm"])
             hm_loss = hm_loss + hm_l / opt.num_stacks
-            r = self.crit_poly(output["poly"], batch["reg_mask"], batch["ind"], batch["poly"],
-                               freq_mask=batch.get("freq_mask"), peak=batch.get("peak"),
-                               hm=output["hm"])
-            if opt.poly_order:
-                poly_loss = poly_loss + r[0] / opt.num_stacks
-                order_loss = order_loss + r[1] / opt.num_stacks
+            if getattr(opt, "cat_spec_poly", False):
+                # :103-106 -> PolyLoss.forward with mask = batch['cat_spec_mask'] [B, M, C*2N]: its per-object test
+                # `if mask[batch][i]:` (models/losses.py:870) is the truth value of a C*2N-element tensor
+                if batch["cat_spec_mask"][0][0].numel() > 1:
+                    raise RuntimeError("Boolean value of Tensor with more than one value is ambiguous")
+                r = self.crit_poly(output["poly"], batch["cat_spec_mask"][:, :, 0], batch["ind"], batch["cat_spec_poly"],
+                                   hm=output["hm"])
+                poly_loss = poly_loss + (r[0] if opt.poly_order else r) / opt.num_stacks
+            elif getattr(opt, "dense_poly", False):
+                poly_loss = poly_loss + dense_poly_l1_loss(output["poly"], batch["dense_poly"],
+                                                           batch["dense_poly_mask"], 1e-4) / opt.num_stacks
             else:
-                poly_loss = poly_loss + r / opt.num_stacks
+                r = self.crit_poly(output["poly"], batch["reg_mask"], batch["ind"], batch["poly"],
+                                   freq_mask=batch.get("freq_mask"), peak=batch.get("peak"),
+                                   hm=output["hm"])
+                if opt.poly_order:
+                    poly_loss = poly_loss + r[0] / opt.num_stacks
+                    order_loss = order_loss + r[1] / opt.num_stacks
+                else:
+                    poly_loss = poly_loss + r / opt.num_stacks
             if opt.reg_offset and opt.off_weight > 0:
                 off_loss = off_loss + self.crit_reg(output["reg"], batch["reg_mask"], batch["ind"],
                                                     batch["reg"]) / opt.num_stacks
@@ -100,7 +115,8 @@ class PolydetTrainer(BaseTrainer):
         h, w = batch["input"].shape[2] // opt.down_ratio, batch["input"].shape[3] // opt.down_ratio
         targets = build_targets(batch, h, w, opt.num_classes, rep=opt.rep,
                                 no_reorder_flip=getattr(opt, "no_reorder_flip", False),
-                                with_border_hm=False)
+                                with_border_hm=False, dense_poly=getattr(opt, "dense_poly", False),
+                                cat_spec_poly=getattr(opt, "cat_spec_poly", False))
         out = {k: v for k, v in batch.items() if k in ("input", "meta")}
         out.update(targets)
         return out

@@ -48,7 +48,7 @@
 extern "C" {
 #endif
 
-#define CP_ABI_VERSION 2
+#define CP_ABI_VERSION 3   /* 3 (round 4): + cp_polydet_decode_ex, cp_dense_l1_*, cp_polydet_dense_targets; no signature changed */
 
 enum {
   CP_OK = 0,
@@ -430,6 +430,15 @@ int cp_polydet_targets(const cp_target_shape* s, const double* bbox_xywh, const 
                        float* wh, float* freq_mask, void* workspace, size_t workspace_bytes,
                        void* stream);
 
+/* `--dense_poly` targets (src/lib/datasets/sample/polydet.py:401-403,429-441 with draw_dense_reg,
+ * src/lib/utils/image.py:176-204): after cp_polydet_targets on the SAME shape and workspace (its per-object
+ * descriptors are read from it), dense_poly [B][2N][h][w] holds, per pixel, the polygon row of the LAST object k (in
+ * annotation order) whose Gaussian there is >= the class-maximum heat map as it stood after drawing objects 0..k
+ * (the comparison the reference makes: float64 Gaussian against the float32 map), 0 where no object qualifies;
+ * dense_mask [B][2N][h][w] = (dense_poly != 0) as 0 / 1 floats.  poly = cp_polydet_targets' poly output. */
+int cp_polydet_dense_targets(const cp_target_shape* s, const float* poly, const void* workspace,
+                             size_t workspace_bytes, float* dense_poly, float* dense_mask, void* stream);
+
 /* --------------------------- fused training BatchNorm2d (+residual) (+ReLU) --
  * y = act(bn(x) + residual) with batch statistics (torch.nn.BatchNorm2d training semantics:
  * biased variance for normalisation, running stats updated with `momentum`, unbiased variance).
@@ -464,6 +473,15 @@ int cp_polydet_decode(const float* heat, const float* polys, const float* depth,
                       int32_t B, int32_t C, int32_t H, int32_t W, int32_t N2, int32_t K,
                       int32_t rep, float* dets, int64_t* inds, int32_t* clses, void* workspace,
                       size_t workspace_bytes, void* stream);
+/* `--cat_spec_poly` (src/lib/models/decode.py:534-537): polys is [B, C * N2, H, W], one polygon of N2 numbers per
+ * class, and a detection of class c takes channels c * N2 .. c * N2 + N2 - 1 (`polys.view(batch, K, cat,
+ * nbr_points).gather(2, clses)`).  cat_spec_poly = 0 is cp_polydet_decode.  (The reference takes `nbr_points` from
+ * `polys.shape[-1]` of the MAP, i.e. its width: its view only succeeds when C * W equals the channel count -- the
+ * Python mirror keeps that precondition, the kernel does not need it.) */
+int cp_polydet_decode_ex(const float* heat, const float* polys, const float* depth, const float* reg,
+                         int32_t B, int32_t C, int32_t H, int32_t W, int32_t N2, int32_t K,
+                         int32_t rep, int32_t cat_spec_poly, float* dets, int64_t* inds, int32_t* clses,
+                         void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------- focal loss --
  * forward: hm[n] <- clamp(sigmoid(hm[n]), 1e-4, 1-1e-4) IN PLACE (the reference
@@ -503,6 +521,15 @@ int cp_mse_forward(const float* x, const float* gt, int64_t n, float* loss_out, 
                    size_t workspace_bytes, void* stream);
 int cp_mse_backward(const float* x, const float* gt, int64_t n, const float* grad_loss, float* grad_x,
                     void* stream);
+
+/* `--dense_poly` loss (src/lib/trains/polydet.py:107-110): torch.nn.L1Loss(reduction='sum')(pred * mask, target * mask)
+ * / (mask.sum() + eps) over whole maps of n elements.  forward: out2[0] = loss, out2[1] = mask.sum() + eps (the
+ * denominator the backward needs); backward: grad_pred = sign(pred * mask - target * mask) * mask * grad_loss[0] / den[0]. */
+size_t cp_dense_l1_workspace_bytes(void);
+int cp_dense_l1_forward(const float* pred, const float* target, const float* mask, int64_t n, float eps, float* out2,
+                        void* workspace, size_t workspace_bytes, void* stream);
+int cp_dense_l1_backward(const float* pred, const float* target, const float* mask, int64_t n, const float* den,
+                         const float* grad_loss, float* grad_pred, void* stream);
 
 /* ----------------------------------- polygon IoU (Weiler-Atherton) + order --
  * feat = polygon head [B,2N,H,W]; per masked object the literal reference

@@ -49,8 +49,10 @@ def gather_feat(feat, ind):
     return torch.gather(f, 2, idx).permute(0, 2, 1).contiguous()
 
 
-def polydet_decode(heat, polys, depth, reg=None, K=100, rep="cartesian"):
-    """decode.py:512-670 (cat_spec_poly=False).  heat is the activated heat map.
+def polydet_decode(heat, polys, depth, reg=None, K=100, rep="cartesian", cat_spec_poly=False):
+    """decode.py:512-670.  heat is the activated heat map.  cat_spec_poly (:534-537): `nbr_points` is the MAP's
+    width (`int(polys.shape[-1])` at :514), polys [B,K,Cp] is viewed as [B,K,cat,width] -- torch raises unless
+    Cp == cat * width -- and the detection's class picks its block.
 
     Returns dets[B,K,2N+7] = [x1,y1,x2,y2,score,cls,poly(2N),depth] and the
     selected flat indices inds[B,K] (int64), classes[B,K] (int32)."""
@@ -65,6 +67,11 @@ def polydet_decode(heat, polys, depth, reg=None, K=100, rep="cartesian"):
         xs = xs.view(B, K, 1) + 0.5
         ys = ys.view(B, K, 1) + 0.5
     p = gather_feat(polys, inds).clone()
+    if cat_spec_poly:
+        cat, nbr_points = heat.shape[1], int(polys.shape[-1])
+        p = p.view(B, K, cat, nbr_points)
+        ci = clses.view(B, K, 1, 1).expand(B, K, 1, nbr_points).long()
+        p = p.gather(2, ci).view(B, K, nbr_points).clone()
     d = gather_feat(depth, inds).view(B, K, 1).float()
     n2 = p.shape[-1]
     if rep in ("polar", "polar_fixed"):

@@ -288,11 +288,20 @@ def poly_loss(output, mask, ind, target, poly_loss="l1", rep="cartesian", poly_o
     return loss
 
 
+def dense_poly_l1(pred, dense_poly, dense_mask):
+    """trains/polydet.py:107-110 (`--dense_poly`): torch.nn.L1Loss(reduction='sum')(pred * mask, target * mask) /
+    (mask.sum() + 1e-4)."""
+    mask_weight = dense_mask.sum() + 1e-4
+    return F.l1_loss(pred * dense_mask, dense_poly * dense_mask, reduction="sum") / mask_weight
+
+
 def polydet_loss(outputs, batch, *, num_stacks=1, poly_loss_kind="l1", rep="cartesian",
                  poly_order=False, hm_weight=1.0, off_weight=1.0, poly_weight=1.0,
-                 depth_weight=0.1, reg_offset=True, reg_loss="l1", mse_loss=False):
-    """trains/polydet.py:38-162 (default switches).  `outputs` = list of dicts of
-    RAW head outputs; returns (loss, stats dict) and leaves outputs untouched."""
+                 depth_weight=0.1, reg_offset=True, reg_loss="l1", mse_loss=False, dense_poly=False,
+                 cat_spec_poly=False):
+    """trains/polydet.py:38-162.  `outputs` = list of dicts of RAW head outputs; returns (loss, stats dict) and leaves
+    outputs untouched.  cat_spec_poly (:103-106): PolyLoss gets the [B,M,C*2N] mask and its `if mask[batch][i]:`
+    (models/losses.py:870) raises RuntimeError on the first object; dense_poly (:107-110): dense masked L1."""
     hm_l = off_l = poly_l = depth_l = order_l = 0
     for s in range(num_stacks):
         o = outputs[s]
@@ -304,13 +313,20 @@ def polydet_loss(outputs, batch, *, num_stacks=1, poly_loss_kind="l1", rep="cart
         else:
             hm = sigmoid_clamp(o["hm"])
             hm_l = hm_l + neg_loss(hm, batch["hm"]) / num_stacks
-        r = poly_loss(o["poly"], batch["reg_mask"], batch["ind"], batch["poly"],
-                      poly_loss_kind, rep, poly_order)
-        if poly_order:
-            poly_l = poly_l + r[0] / num_stacks
-            order_l = order_l + r[1] / num_stacks
+        if cat_spec_poly:
+            if bool(batch["cat_spec_mask"][0][0]):       # raises for a row of more than one element, as the reference
+                pass
+            raise NotImplementedError("single-element cat_spec_mask rows: the reference's accidental 1x1 case")
+        elif dense_poly:
+            poly_l = poly_l + dense_poly_l1(o["poly"], batch["dense_poly"], batch["dense_poly_mask"]) / num_stacks
         else:
-            poly_l = poly_l + r / num_stacks
+            r = poly_loss(o["poly"], batch["reg_mask"], batch["ind"], batch["poly"],
+                          poly_loss_kind, rep, poly_order)
+            if poly_order:
+                poly_l = poly_l + r[0] / num_stacks
+                order_l = order_l + r[1] / num_stacks
+            else:
+                poly_l = poly_l + r / num_stacks
         if reg_offset and off_weight > 0:
             off_l = off_l + reg_crit(o["reg"], batch["reg_mask"], batch["ind"],
                                      batch["reg"]) / num_stacks

@@ -12,8 +12,11 @@ stand-ins for the absent cv2, the targets do not depend on pixel values), seven 
 random crop / shift, mirroring with and without vertex re-ordering, polar and polar_fixed;
 tests/test_targets.py::test_object_loop_matches_reference_sampler holds every array bit-exact.
 
-Not restated (flags the accelerated path refuses): --elliptical_gt, --mse_loss, --dense_poly,
---cat_spec_poly; `fg` (a warped instance image) is an input the loss never reads.
+Round 4: --dense_poly (draw_dense_reg, utils/image.py:176-204, called at sample/polydet.py:401-403; dict edit :429-441)
+and --cat_spec_poly (:245-248, 288-291, 424-425) are restated too and pinned by sampler_cart_dense.npz /
+sampler_cart_catspec.npz (the reference's own __getitem__ with those flags).
+Not restated (flags the accelerated path refuses): --elliptical_gt, --mse_loss; `fg` (a warped instance image) is an
+input the loss never reads.
 """
 import math
 
@@ -65,6 +68,29 @@ def draw_umich_gaussian(heatmap, center, radius, k=1):
     return heatmap
 
 
+def draw_dense_reg(regmap, heatmap, center, value, radius):
+    """utils/image.py:176-204 (is_offset=False): inside the object's splat window, regmap <- value wherever the
+    float64 Gaussian is >= the (float32) class-maximum heat map."""
+    diameter = 2 * radius + 1
+    gaussian = gaussian2D((diameter, diameter), sigma=diameter / 6)
+    value = np.array(value, dtype=np.float32).reshape(-1, 1, 1)
+    dim = value.shape[0]
+    reg = np.ones((dim, diameter * 2 + 1, diameter * 2 + 1), dtype=np.float32) * value
+    x, y = int(center[0]), int(center[1])
+    height, width = heatmap.shape[0:2]
+    left, right = min(x, radius), min(width - x, radius + 1)
+    top, bottom = min(y, radius), min(height - y, radius + 1)
+    masked_heatmap = heatmap[y - top:y + bottom, x - left:x + right]
+    masked_regmap = regmap[:, y - top:y + bottom, x - left:x + right]
+    masked_gaussian = gaussian[radius - top:radius + bottom, radius - left:radius + right]
+    masked_reg = reg[:, radius - top:radius + bottom, radius - left:radius + right]
+    if min(masked_gaussian.shape) > 0 and min(masked_heatmap.shape) > 0:
+        idx = (masked_gaussian >= masked_heatmap).reshape(1, masked_gaussian.shape[0], masked_gaussian.shape[1])
+        masked_regmap = (1 - idx) * masked_regmap + idx * masked_reg
+    regmap[:, y - top:y + bottom, x - left:x + right] = masked_regmap
+    return regmap
+
+
 def affine_transform(pt, t):
     """utils/image.py:62-65: the point is cast to float32, the product runs in float64."""
     new_pt = np.array([pt[0], pt[1], 1.], dtype=np.float32).T
@@ -73,7 +99,7 @@ def affine_transform(pt, t):
 
 
 def build_targets(anns, trans_output, flipped, width, output_h, output_w, num_classes, max_objs,
-                  nbr_points, rep="cartesian", no_reorder_flip=False):
+                  nbr_points, rep="cartesian", no_reorder_flip=False, dense_poly=False, cat_spec_poly=False):
     """One image.  anns: list of dicts {bbox: [x,y,w,h], poly: [2N numbers], cls_id: int,
     pseudo_depth: float, freq: float (the class frequency the reference looks up by name)}.
     Returns the sample dict of sample/polydet.py:425-449 (without 'input' and 'fg')."""
@@ -88,6 +114,9 @@ def build_targets(anns, trans_output, flipped, width, output_h, output_w, num_cl
     peak = np.zeros((max_objs, 2), dtype=np.float32)
     reg_mask = np.zeros((max_objs), dtype=np.uint8)
     freq_mask = np.zeros((max_objs), dtype=np.float32)
+    dense = np.zeros((nbr_points * 2, output_h, output_w), dtype=np.float32)
+    cs_poly = np.zeros((max_objs, num_classes * nbr_points * 2), dtype=np.float32)
+    cs_mask = np.zeros((max_objs, num_classes * nbr_points * 2), dtype=np.uint8)
     for k in range(num_objs):
         ann = anns[k]
         box = ann["bbox"]
@@ -146,6 +175,10 @@ def build_targets(anns, trans_output, flipped, width, output_h, output_w, num_cl
                         theta = theta + 2 * math.pi
                     poly[k][i] = r
                     poly[k][i + 1] = theta
+                if cat_spec_poly:                      # :245-248 / :288-291: the same two numbers in the class's block
+                    o = cls_id * (nbr_points * 2) + i
+                    cs_poly[k][o], cs_poly[k][o + 1] = poly[k][i], poly[k][i + 1]
+                    cs_mask[k][o:o + 2] = 1
             peak[k] = ct
             ind[k] = ct_int[1] * output_w + ct_int[0]
             reg[k] = ct - ct_int
@@ -154,9 +187,21 @@ def build_targets(anns, trans_output, flipped, width, output_h, output_w, num_cl
             else:
                 reg_mask[k] = 1
             freq_mask[k] = ann["freq"]
+            if dense_poly:                             # :401-403
+                draw_dense_reg(dense, hm.max(axis=0), ct_int, poly[k], radius)
     if np.count_nonzero(freq_mask) == 0:
         freq_mean = 1.0
     else:
         freq_mean = np.sum(freq_mask) / (np.count_nonzero(freq_mask))
-    return {"hm": hm, "reg_mask": reg_mask, "ind": ind, "poly": poly, "pseudo_depth": pseudo_depth,
-            "freq_mask": freq_mean, "border_hm": border_hm, "wh": wh, "peak": peak, "reg": reg}
+    if cat_spec_poly:                                  # :424-425: this dict has no freq_mask / border_hm / wh
+        ret = {"hm": hm, "reg_mask": reg_mask, "ind": ind, "poly": poly, "cat_spec_poly": cs_poly,
+               "cat_spec_mask": cs_mask, "pseudo_depth": pseudo_depth, "peak": peak, "reg": reg}
+    else:
+        ret = {"hm": hm, "reg_mask": reg_mask, "ind": ind, "poly": poly, "pseudo_depth": pseudo_depth,
+               "freq_mask": freq_mean, "border_hm": border_hm, "wh": wh, "peak": peak, "reg": reg}
+    if dense_poly:                                     # :429-441
+        dmask = dense.copy()
+        dmask[dmask != 0] = 1
+        ret.update({"dense_poly": dense, "dense_poly_mask": dmask})
+        del ret["poly"]
+    return ret

@@ -101,3 +101,35 @@ def net_input(kind):
 
 
 POST_META = dict(c=np.array([1024.0, 512.0], dtype=np.float32), s=2048.0)
+
+
+# ---- round 4: --cat_spec_poly / --dense_poly (decode.py:534-537, trains/polydet.py:103-110) -------------------------
+CATSPEC_DECODE = ("catspec16", 2, 8, 24, 32, 16, 32)        # name, B, C, h, w (= 2N: the reference's view needs it), N, K
+
+
+def catspec_decode_inputs_np(name, B, C, h, w, N, K):
+    heat = _sigmoid_f32(synth.heat_logits("dec/%s/hm" % name, B, C, h, w))
+    polys = synth.normal("dec/%s/poly" % name, (B, C * 2 * N, h, w), 0.0, 8.0)
+    depth = synth.uniform("dec/%s/depth" % name, (B, 1, h, w))
+    reg = synth.uniform("dec/%s/reg" % name, (B, 2, h, w))
+    return heat, polys, depth, reg
+
+
+DENSE_LOSS = ("dense16", 2, 16, 24, 40)                       # name, B, N, h, w
+
+
+def dense_loss_inputs_np(name, B, N, h, w):
+    """pred / dense_poly / dense_poly_mask [B, 2N, h, w]: blobs of constant polygon rows like draw_dense_reg leaves,
+    a mask that is 1 exactly where the target is non-zero, and a few pred == target elements (sign(0) = 0)."""
+    pred = synth.normal("dloss/%s/pred" % name, (B, 2 * N, h, w), 0.0, 3.0)
+    tgt = np.zeros((B, 2 * N, h, w), np.float32)
+    rows = synth.normal("dloss/%s/rows" % name, (B, 6, 2 * N), 0.0, 6.0)
+    cen = synth.integers("dloss/%s/cen" % name, (B, 6, 3), 2, 20)
+    for b in range(B):
+        for k in range(6):
+            cy, cx, r = int(cen[b, k, 0]), int(cen[b, k, 1]) * 2 % w, 1 + int(cen[b, k, 2]) % 4
+            tgt[b, :, max(cy - r, 0):cy + r + 1, max(cx - r, 0):cx + r + 1] = rows[b, k][:, None, None]
+    tgt[:, 3] = 0.0                                       # a channel whose target is 0 everywhere: masked out
+    mask = (tgt != 0).astype(np.float32)
+    pred[0, 0, :4, :4] = tgt[0, 0, :4, :4]                # exact hits
+    return pred, tgt, mask

@@ -71,6 +71,10 @@ CASES = [
     ("polar_flip", "polar", "train", False, 1.0, False, [3, 4, 5], 15),
     ("polar_fixed", "polar_fixed", "train", False, 0.5, False, [6, 7], 16),
     ("cart_val", "cartesian", "val", False, 0.0, False, [0, 9], 17),
+    # round 4: the two switches of sample/polydet.py:245-248 / 401-403 (a 9th field = extra opt flags)
+    ("cart_dense", "cartesian", "train", False, 0.5, False, [0, 2, 5], 18, {"dense_poly": True}),
+    ("cart_catspec", "cartesian", "train", False, 0.5, False, [1, 3], 19, {"cat_spec_poly": True}),
+    ("polar_catspec", "polar", "train", False, 0.0, False, [4], 20, {"cat_spec_poly": True}),
 ]
 
 
@@ -96,22 +100,35 @@ def main():
             self.coco = index
             self.images = sorted(index.imgs)
 
-    for name, rep, split, not_rand_crop, flip, no_reorder, ids, seed in CASES:
+    only = set(sys.argv[1:])
+    for case in CASES:
+        name, rep, split, not_rand_crop, flip, no_reorder, ids, seed = case[:8]
+        extra = case[8] if len(case) > 8 else {}
+        if only and name not in only:
+            continue
         opt = types.SimpleNamespace(
             nbr_points=16, keep_res=False, pad=31, input_h=384, input_w=1280, down_ratio=4, not_rand_crop=not_rand_crop,
             scale=0.4, shift=0.1, flip=flip, no_color_aug=True, mse_loss=False, elliptical_gt=False, hm_gauss=4,
             rep=rep, cat_spec_poly=False, dense_poly=False, no_reorder_flip=no_reorder, debug=1, reg_offset=True)
+        for k, v in extra.items():
+            setattr(opt, k, v)
         ds = DS(opt, split)
         out = {"rep": np.array(rep), "split": np.array(split), "no_reorder_flip": np.array(no_reorder), "seed": np.array(seed),
                "not_rand_crop": np.array(not_rand_crop), "flip_prob": np.array(flip), "scale": np.array(0.4), "shift": np.array(0.1),
                "img_ids": np.array(ids), "img_hw": np.array([IMG_H, IMG_W]), "out_hw": np.array([384 // 4, 1280 // 4]),
-               "class_freq": np.array([ds.class_frequencies[n] for n in ds.class_name[1:]], np.float64)}
+               "class_freq": np.array([ds.class_frequencies[n] for n in ds.class_name[1:]], np.float64),
+               "dense_poly": np.array(bool(extra.get("dense_poly", False))),
+               "cat_spec_poly": np.array(bool(extra.get("cat_spec_poly", False)))}
         np.random.seed(seed)
         for j, i in enumerate(ids):
             r = ds[i]
-            for k in ("hm", "reg_mask", "ind", "poly", "pseudo_depth", "border_hm", "wh", "peak", "reg"):
-                out["s%d_%s" % (j, k)] = np.asarray(r[k])
-            out["s%d_freq_mask" % j] = np.float64(r["freq_mask"])
+            for k in ("hm", "reg_mask", "ind", "poly", "pseudo_depth", "border_hm", "wh", "peak", "reg", "cat_spec_poly",
+                      "cat_spec_mask", "dense_poly", "dense_poly_mask"):
+                if k in r:                       # (the cat-spec dict has no border_hm / wh / freq_mask, the dense one no poly)
+                    out["s%d_%s" % (j, k)] = np.asarray(r[k])
+            out["s%d_keys" % j] = np.array(sorted(k for k in r if k not in ("input", "meta", "fg")))
+            if "freq_mask" in r:
+                out["s%d_freq_mask" % j] = np.float64(r["freq_mask"])
             out["s%d_c" % j] = np.asarray(r["meta"]["c"], np.float32)        # what the draws came to
             out["s%d_s" % j] = np.float64(r["meta"]["s"])
             out["s%d_gt_det" % j] = np.asarray(r["meta"]["gt_det"])

@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(L, s), "missing export " + s
     assert set(syms) == set(_C.EXPORTS)
-    assert L.cp_abi_version() == 2
+    assert L.cp_abi_version() == _C.ABI_VERSION == 3
     assert L.cp_build_arch() == b"gfx950"
     assert L.cp_strerror(-2) == b"unsupported shape or option"
 

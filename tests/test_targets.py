@@ -191,7 +191,8 @@ def test_targets_edge_cases():
 # ---------------------------------------------------------------------------------------------------------------------
 # The object loop against the REFERENCE's own PolydetDataset.__getitem__ (tests/golden/sampler_*.npz, made by
 # tests/golden/gen_sampler_golden.py running src/lib/datasets/sample/polydet.py:66-449 on KITTIPolyStuff/BBoxes/val16.json)
-SAMPLER_CASES = ["cart_crop", "cart_flip", "cart_shift", "cart_noreorder", "polar_flip", "polar_fixed", "cart_val"]
+SAMPLER_CASES = ["cart_crop", "cart_flip", "cart_shift", "cart_noreorder", "polar_flip", "polar_fixed", "cart_val",
+                 "cart_dense", "cart_catspec", "polar_catspec"]       # the last three: --dense_poly / --cat_spec_poly
 CLASS_NAMES = ["person", "rider", "car", "truck", "bus", "train", "motorcycle", "bicycle"]
 
 
@@ -247,12 +248,22 @@ def test_object_loop_matches_reference_sampler(case, golden):
     for j, (c, s, flipped) in enumerate(_replay_draws(g, n)):
         assert np.array_equal(c, g["s%d_c" % j]) and float(s) == float(g["s%d_s" % j]), (j, c, s)
         t = opost.get_affine_transform(c, s, 0, [ow, oh])
+        dense, catspec = bool(g.get("dense_poly", False)), bool(g.get("cat_spec_poly", False))
         r = otg.build_targets(_sampler_anns(g, j), t, flipped, W, oh, ow, 8, 128, 16, str(g["rep"]),
-                              no_reorder_flip=bool(g["no_reorder_flip"]))
-        for k in ("hm", "reg_mask", "ind", "poly", "pseudo_depth", "border_hm", "wh", "peak", "reg"):
-            assert np.array_equal(r[k], g["s%d_%s" % (j, k)]), (case, j, k)
-        assert float(r["freq_mask"]) == float(g["s%d_freq_mask" % j])
+                              no_reorder_flip=bool(g["no_reorder_flip"]), dense_poly=dense, cat_spec_poly=catspec)
+        if "s%d_keys" % j in g:                       # the dict's key set (cat-spec: no freq_mask / border_hm / wh; dense: no poly)
+            assert sorted(r) == sorted(str(k) for k in g["s%d_keys" % j]), (case, sorted(r))
+        for k in ("hm", "reg_mask", "ind", "poly", "pseudo_depth", "border_hm", "wh", "peak", "reg", "cat_spec_poly",
+                  "cat_spec_mask", "dense_poly", "dense_poly_mask"):
+            assert (k in r) == ("s%d_%s" % (j, k) in g), (case, j, k)
+            if k in r:
+                assert np.array_equal(r[k], g["s%d_%s" % (j, k)]), (case, j, k)
+                assert r[k].dtype == g["s%d_%s" % (j, k)].dtype, (case, j, k)
+        if "freq_mask" in r:
+            assert float(r["freq_mask"]) == float(g["s%d_freq_mask" % j])
         assert int(r["reg_mask"].sum()) > 0
+        if dense:
+            assert 0 < float(r["dense_poly_mask"].mean()) < 0.5
 
 
 @pytest.mark.gpu
@@ -270,12 +281,30 @@ def test_device_targets_match_reference_sampler(case, golden):
         t = opost.get_affine_transform(c, s, 0, [ow, oh])
         packed.append(pack_annotations(_sampler_anns(g, j), t, flipped, W, 128, 16))
     raw = {k: v.cuda() for k, v in collate(packed).items()}
-    out = build_targets(raw, oh, ow, 8, rep=str(g["rep"]), no_reorder_flip=bool(g["no_reorder_flip"]))
+    dense, catspec = bool(g.get("dense_poly", False)), bool(g.get("cat_spec_poly", False))
+    out = build_targets(raw, oh, ow, 8, rep=str(g["rep"]), no_reorder_flip=bool(g["no_reorder_flip"]), dense_poly=dense,
+                        cat_spec_poly=catspec)
     for j in range(n):
-        for k in ("reg_mask", "ind", "hm", "border_hm"):
-            assert np.array_equal(out[k][j].cpu().numpy(), g["s%d_%s" % (j, k)]), (case, j, k)
-        for k in ("poly", "pseudo_depth", "wh", "peak", "reg"):
-            ref = g["s%d_%s" % (j, k)]
-            np.testing.assert_allclose(out[k][j].cpu().numpy(), ref, rtol=2.4e-7, atol=1e-6 * max(1.0, np.abs(ref).max()),
-                                       err_msg="%s %d %s" % (case, j, k))
-        np.testing.assert_allclose(float(out["freq_mask"][j]), float(g["s%d_freq_mask" % j]), rtol=1e-6)
+        if "s%d_keys" % j in g:
+            assert sorted(out) == sorted(str(k) for k in g["s%d_keys" % j]), (case, sorted(out))
+        for k in ("reg_mask", "ind", "hm", "border_hm", "cat_spec_mask"):
+            if k in out:
+                assert np.array_equal(out[k][j].cpu().numpy(), g["s%d_%s" % (j, k)]), (case, j, k)
+        for k in ("poly", "pseudo_depth", "wh", "peak", "reg", "cat_spec_poly"):
+            if k in out:
+                ref = g["s%d_%s" % (j, k)]
+                np.testing.assert_allclose(out[k][j].cpu().numpy(), ref, rtol=2.4e-7, atol=1e-6 * max(1.0, np.abs(ref).max()),
+                                           err_msg="%s %d %s" % (case, j, k))
+        if "freq_mask" in out:
+            np.testing.assert_allclose(float(out["freq_mask"][j]), float(g["s%d_freq_mask" % j]), rtol=1e-6)
+        if dense:
+            # which object owns a pixel is decided by `float64 Gaussian >= float32 map` (utils/image.py:201): the kernel's
+            # exp may differ from numpy's in the last bit of the double, which flips that test only where the Gaussian sits
+            # within one ulp of a float32 grid point -- allow a handful of such pixels, everything else is exact
+            ref_m, got_m = g["s%d_dense_poly_mask" % j], out["dense_poly_mask"][j].cpu().numpy()
+            ref_d, got_d = g["s%d_dense_poly" % j], out["dense_poly"][j].cpu().numpy()
+            px_diff = (ref_m != got_m).any(axis=0)
+            assert px_diff.sum() <= 2, (case, j, int(px_diff.sum()))
+            same = ~px_diff
+            np.testing.assert_allclose(got_d[:, same], ref_d[:, same], rtol=2.4e-7, atol=1e-5)
+            assert ref_m.sum() > 0 and set(np.unique(got_m)) <= {0.0, 1.0}
