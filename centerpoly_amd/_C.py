@@ -187,10 +187,15 @@ class _ZeroPool(object):
     block: one fill kernel per BLOCK bytes handed out instead of one per tensor (the training step asks for ~190 of
     them, most a few KB -- each a launch of its own).  A block is never reused: a fresh one is allocated when the
     current one is used up, and the caching allocator recycles a block only once every tensor carved from it has died,
-    so a gradient that outlives the step keeps its memory."""
-    BLOCK = 64 << 20
+    so a gradient that outlives the step keeps its memory -- and pins its whole block: tensors from `zeros` are meant to
+    die within the step (autograd's grad accumulation copies or adopts them; a retained .grad keeps 32 MB alive, not
+    more).  `release()` drops the current block (trainer teardown, train() / eval() switches)."""
+    BLOCK = 32 << 20
 
     def __init__(self):
+        self.block, self.off, self.key = None, 0, None
+
+    def release(self):
         self.block, self.off, self.key = None, 0, None
 
     def take(self, shape, device):
@@ -200,7 +205,10 @@ class _ZeroPool(object):
         nbytes = (n * 4 + 255) // 256 * 256
         if nbytes > self.BLOCK // 8 or n == 0:
             return torch.zeros(tuple(shape), dtype=torch.float32, device=device)
-        key = (torch.device(device), torch.cuda.current_stream(device).cuda_stream)
+        dev = torch.device(device)
+        if dev.type == "cuda" and dev.index is None:     # 'cuda' and 'cuda:0' are one device: one key, one block
+            dev = torch.device("cuda", torch.cuda.current_device())
+        key = (dev, torch.cuda.current_stream(dev).cuda_stream)
         if self.block is None or self.key != key or self.off + nbytes > self.BLOCK:
             self.block = torch.zeros(self.BLOCK // 4, dtype=torch.float32, device=device)
             self.off, self.key = 0, key
@@ -213,8 +221,13 @@ _zero_pool = _ZeroPool()
 
 
 def zeros(shape, device):
-    """float32 zeros on a HIP device for a kernel to accumulate into (see _ZeroPool)."""
+    """float32 zeros on a HIP device for a kernel to accumulate into (see _ZeroPool).  Not to be retained past the step."""
     return _zero_pool.take(shape, device)
+
+
+def release_zero_pool():
+    """Drop the pool's current block (its memory returns to the allocator once the tensors carved from it have died)."""
+    _zero_pool.release()
 
 
 class _NoEvent(object):

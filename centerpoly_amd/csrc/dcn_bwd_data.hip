@@ -21,13 +21,18 @@
 // ((TH+6) x 22 cells per channel, coalesced row loads), the bilinear algebra for grad_mask /
 // grad_offset (register sums over the lane's channels, shuffled together once per tile), and 4
 // grad_x contributions accumulated in a matching LDS region in 64-bit fixed point.
-//   * fixed point: contribution -> fma((double)gcol*m, (double)w*scale, 2^52+2^51); the raw bits of
-//     that double are added with ds_add_u64 (LDS float atomics run 25x slower on gfx950,
-//     tools/micro/lds_atomic_rate.hip).  Every add carries the constant 0x4338<<48 in its top 16
-//     bits and the rounded integer in two's complement below, so the low 48 bits of the cell are the
-//     exact integer sum whatever the number and order of adds; `scale` = 2^35 / (a bound of |gcol|
-//     from the tile's max L1 norm of grad_out and max|W|) leaves 2^12 adds of headroom (a cell gets
-//     at most TH*16*9 = 1152).  Order-independent, i.e. run-to-run deterministic.
+//   * fixed point (round 4: 32-bit): contribution -> (int)rint(gcol * m * w * scale), added with ds_add_u32 (LDS float
+//     atomics run 25x slower on gfx950, tools/micro/lds_atomic_rate.hip; round 2-3 used 64-bit cells with a scale from
+//     an L1 bound of grad_out -- the 8-byte atomics took twice the LDS passes of a dword atomic and 52 % of their
+//     cycles were bank conflicts).  `scale` is a power of two chosen per tile AND chunk from the chunk's ACTUAL largest
+//     |gcol * m| (a wave / workgroup max over the accumulators right after the matrix phase): the largest contribution
+//     maps to < 2^20, a cell receives at most TH*16*9 <= 1728 < 2^11 adds, so the two's-complement sum cannot wrap and
+//     is exact whatever the number and order of adds; one add is off by at most 2^-21 of the chunk's largest column
+//     value.  Order-independent, i.e. run-to-run deterministic.  With the exact-f32 arithmetic (flag
+//     CP_DCN_BWD_EXACT_F32, template BF = false) the cells stay 64 bits wide as in rounds 2-3: contribution ->
+//     fma((double)gcol*m, (double)w*scale, 2^52+2^51), raw bits added with ds_add_u64 -- every add carries 0x4338<<48 in
+//     its top 16 bits and the rounded integer in two's complement below, the largest column value maps below 2^35: one
+//     add is off by at most 2^-36 of it, finer than the fp32 rounding of the product itself.
 //   * flush: after each chunk the region sums are written with PLAIN coalesced stores to the
 //     tile's slab in the caller's workspace; a second kernel adds, for every grad_x element, the
 //     (at most four) slabs whose region covers it, in a fixed order.  No global float atomics on
@@ -60,7 +65,9 @@ constexpr int KC = 16;                     // channels per chunk: one MFMA m-til
 constexpr int HALO = 3;                    // region halo in pixels (offsets within +-2 px stay in LDS)
 constexpr int A_F4 = TAPS * 4 * 64;        // float4 elements of one weight stage (64 co x 16 c x 9 taps)
 constexpr unsigned OOB = 0x80000000u;      // buffer offset past every tensor (reads 0)
-constexpr double FX_MAGIC = 6755399441055744.0;   // 2^52 + 2^51
+constexpr int FX_BITS = 20;                // 32-bit cells: the chunk's largest |gcol * m| maps below 2^20 (<= 2^11 adds per cell)
+constexpr int FX_BITS_WIDE = 35;           // 64-bit cells (exact-f32 arithmetic): below 2^35, 48-bit sums
+constexpr double FX_MAGIC = 6755399441055744.0;   // 2^52 + 2^51: fma(x, s, FX_MAGIC) holds rint(x * s) in its low 48 bits
 
 constexpr int HALO_L = 4;                  // columns left of the tile: the tile's own 16 columns start 16-B aligned
 constexpr int RWD = 24;                    // region row: 4 + 16 + 4 columns (x offsets within about +-3 px)
@@ -194,7 +201,9 @@ __global__ __launch_bounds__(TH * 64, TH / 4) void dcn_bwd_data2_kernel(D2Args a
   static_assert(DBUF || NS == 1, "the single-buffer schedule is written for one slab per chunk");
   __shared__ f32x4 Abuf[DBUF ? 2 : 1][A_F4];               // weights of one (chunk, slab), fragment order
   __shared__ float xreg[KC * RSZP];                        // input region of the chunk's channels
-  __shared__ __attribute__((aligned(16))) unsigned long long gacc[WANT_GX ? KC * RSZP : 2];  // fixed-point grad_x region sums
+  constexpr bool WIDE = !BF;                               // 64-bit cells under the exact-f32 arithmetic
+  using cell_t = typename std::conditional<WIDE, unsigned long long, unsigned>::type;
+  __shared__ __attribute__((aligned(16))) cell_t gacc[WANT_GX ? KC * RSZP : 4];   // fixed-point grad_x region sums
   __shared__ float4 rec[TAPS * NPX];                       // per (tap, pixel): ly, lx, mask, region index
   __shared__ float wred[TH];
 
@@ -269,15 +278,12 @@ __global__ __launch_bounds__(TH * 64, TH / 4) void dcn_bwd_data2_kernel(D2Args a
   // per tile; the weights are split by the prologue kernel, so the matrix phase carries no conversion at all.
   float breg[BF ? 1 : NB];
   bf16x8 bh[BF ? NS * 2 : 1], bl[BF ? NS * 2 : 1];
-  float l1_lane = 0.f;
   if constexpr (!BF) {
     const unsigned gbase = p_ok ? ((unsigned)g * (unsigned)HW + (unsigned)p) * 4u : OOB;
     const unsigned gstep = p_ok ? (unsigned)HW * 16u : 0u;          // 4 output channels
 #pragma unroll
-    for (int q = 0; q < NB; ++q) {                                  // rows past Cout read 0
+    for (int q = 0; q < NB; ++q)                                    // rows past Cout read 0
       breg[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_go, gbase + (unsigned)q * gstep, 0, 0));
-      l1_lane += fabsf(breg[q]);
-    }
   } else {
     const unsigned gstep = p_ok ? (unsigned)HW * 4u : 0u;           // 1 output channel
 #pragma unroll
@@ -286,48 +292,58 @@ __global__ __launch_bounds__(TH * 64, TH / 4) void dcn_bwd_data2_kernel(D2Args a
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const float v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_go, gbase + (unsigned)j * gstep, 0, 0));
-        l1_lane += fabsf(v);
         const __bf16 h = (__bf16)v;
         bh[kk][j] = h;
         bl[kk][j] = (__bf16)(v - (float)h);
       }
     }
   }
-  // fixed-point scale from a bound of |gcol|: max over the tile's pixels of sum_co |go| times max |W|
-  double fx_scale = 0.0, fx_inv = 0.0;
+  // largest |mask| of the wave's pixels (>= 1): the chunk's column maximum times this bounds |gcol * m|
+  float fx_scale = 0.f, fx_inv = 0.f;
   if (WANT_GX) {
-    float l1 = l1_lane;
-    l1 += __shfl_xor(l1, 16, 64);
-    l1 += __shfl_xor(l1, 32, 64);
-    // (fmaxf drops a NaN operand: nan_max keeps it, so that a non-finite grad_out reaches the scale test below)
-    auto nan_max = [](float p, float q) { return p != p ? p : (q != q ? q : fmaxf(p, q)); };
-#pragma unroll
-    for (int o = 8; o > 0; o >>= 1) l1 = nan_max(l1, __shfl_xor(l1, o, 64));
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) lane_mmax = fmaxf(lane_mmax, __shfl_xor(lane_mmax, o, 64));
-    if (lane == 0) wred[wid] = l1 * lane_mmax;
-    for (int e = tid; e < KC * RSZP; e += NTHR) gacc[e] = 0ull;
+    for (int e = tid; e < KC * RSZP; e += NTHR) gacc[e] = 0;
   }
   const unsigned long long t_b0 = CP_T();
   (void)t_b0;
-  __syncthreads();                                                  // rec, wred, gacc initialised
-  if (WANT_GX) {
-    float l1 = wred[0];
+  __syncthreads();                                                  // rec, gacc initialised
+  // Fixed-point scale of a chunk: after its matrix phase every wave leaves max |acc| * mask-max in wred[], the barrier
+  // that publishes the input region publishes these too, and every lane derives the same power of two.
+  auto publish_colmax = [&](const f32x4 (&acc_)[TAPS]) __attribute__((always_inline)) {
+    auto nan_max = [](float p, float q) { return p != p ? p : (q != q ? q : fmaxf(p, q)); };   // (fmaxf drops a NaN)
+    float m_ = 0.f;
 #pragma unroll
-    for (int i = 1; i < TH; ++i) l1 = (l1 != l1) ? l1 : (wred[i] != wred[i] ? wred[i] : fmaxf(l1, wred[i]));
-    const float gb = l1 * a.wmax[0] * 1.0001f;
+    for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) m_ = nan_max(m_, fabsf(acc_[t][r]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m_ = nan_max(m_, __shfl_xor(m_, o, 64));
+    if (lane == 0) wred[wid] = m_ * lane_mmax;
+  };
+  auto derive_scale = [&]() __attribute__((always_inline)) {
+    float cm = wred[0];
+#pragma unroll
+    for (int i = 1; i < TH; ++i) cm = (cm != cm) ? cm : (wred[i] != wred[i] ? wred[i] : fmaxf(cm, wred[i]));
+    const float gb = cm * 1.0001f;
     if (gb > 0.f && gb < 3.0e38f) {
       int ge = 0;
-      (void)frexpf(gb, &ge);
-      fx_scale = ldexp(1.0, 35 - ge);
-      fx_inv = ldexp(1.0, ge - 35);
-    } else if (!(gb == 0.f)) {
-      // grad_out of this tile holds Inf / NaN (a loss overflow): no fixed-point scale exists.  The sums stay 0 and
-      // the flush multiplies them by NaN, so the tile's grad_x comes out NaN, as the reference's float chain would,
+      (void)frexpf(gb, &ge);                                        // gb < 2^ge
+      ge = max(ge, -80);                                            // (the scale stays a finite float for vanishing gradients)
+      constexpr int FXB = WIDE ? FX_BITS_WIDE : FX_BITS;
+      fx_scale = ldexpf(1.f, FXB - ge);
+      fx_inv = ldexpf(1.f, ge - FXB);
+    } else if (gb == 0.f) {
+      fx_scale = 0.f;
+      fx_inv = 0.f;
+    } else {
+      // the chunk's columns hold Inf / NaN (a loss overflow): no fixed-point scale exists.  The sums stay 0 and the
+      // flush multiplies them by NaN, so the tile's grad_x comes out NaN, as the reference's float chain would,
       // instead of silently zero (grad_offset / grad_mask carry the NaN through their float sums anyway).
-      fx_inv = __builtin_nan("");
+      fx_scale = 0.f;
+      fx_inv = __builtin_nanf("");
     }
-  }
+  };
 
   // ---- staging ----
   // Weights: LDS-DMA (global_load_lds_dwordx4), no registers: a stage is 36 pieces of 1 KB (64 lanes x
@@ -389,7 +405,7 @@ __global__ __launch_bounds__(TH * 64, TH / 4) void dcn_bwd_data2_kernel(D2Args a
   constexpr int NQ = KC * RSZ / 4;                                  // 4-cell groups of the chunk's regions
   constexpr int XQ = (NQ + NTHR - 1) / NTHR;
   static_assert(RSZ % 4 == 0 && RSZP % 4 == 0, "flush moves aligned groups of four cells");
-  auto flush = [&](int c0) {                                        // region sums -> slab, plain coalesced stores
+  auto flush = [&](int c0, float inv) {                             // region sums -> slab, plain coalesced stores
     float* dst = slab_tile + (long long)c0 * RSZ;
 #pragma unroll
     for (int i = 0; i < XQ; ++i) {
@@ -398,16 +414,29 @@ __global__ __launch_bounds__(TH * 64, TH / 4) void dcn_bwd_data2_kernel(D2Args a
       if (q < NQ) {
         const int c = q / (RSZ / 4);
         const int l = c * RSZP + (q - c * (RSZ / 4)) * 4;
-        typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
-        u64x2* gp = reinterpret_cast<u64x2*>(&gacc[l]);
-        const u64x2 a0 = gp[0], a1 = gp[1];
-        gp[0] = u64x2{0ull, 0ull};
-        gp[1] = u64x2{0ull, 0ull};
         f32x4 o;
-        o.x = (float)((double)(((long long)(a0.x << 16)) >> 16) * fx_inv);   // low 48 bits, sign-extended
-        o.y = (float)((double)(((long long)(a0.y << 16)) >> 16) * fx_inv);
-        o.z = (float)((double)(((long long)(a1.x << 16)) >> 16) * fx_inv);
-        o.w = (float)((double)(((long long)(a1.y << 16)) >> 16) * fx_inv);
+        if constexpr (WIDE) {
+          typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+          u64x2* gp = reinterpret_cast<u64x2*>(&gacc[l]);
+          const u64x2 a0 = gp[0], a1 = gp[1];
+          gp[0] = u64x2{0ull, 0ull};
+          gp[1] = u64x2{0ull, 0ull};
+          const double dinv = (double)inv;
+          o.x = (float)((double)(((long long)(a0.x << 16)) >> 16) * dinv);   // low 48 bits, sign-extended
+          o.y = (float)((double)(((long long)(a0.y << 16)) >> 16) * dinv);
+          o.z = (float)((double)(((long long)(a1.x << 16)) >> 16) * dinv);
+          o.w = (float)((double)(((long long)(a1.y << 16)) >> 16) * dinv);
+        } else {
+          typedef int i32x4 __attribute__((ext_vector_type(4)));
+          i32x4* gp = reinterpret_cast<i32x4*>(&gacc[l]);
+          const i32x4 a0 = gp[0];
+          gp[0] = i32x4{0, 0, 0, 0};
+          o.x = (float)a0.x * inv;                                  // |sum| < 2^31: one rounding to fp32, then an exact scaling
+          o.y = (float)a0.y * inv;
+          o.z = (float)a0.z * inv;
+          o.w = (float)a0.w * inv;
+        }
+        if (inv != inv) o = f32x4{inv, inv, inv, inv};              // (non-finite chunk: see derive_scale)
         if (c0 + c < a.Cin) *reinterpret_cast<f32x4*>(dst + 4 * q) = o;
       }
     }
@@ -489,13 +518,6 @@ __global__ __launch_bounds__(TH * 64, TH / 4) void dcn_bwd_data2_kernel(D2Args a
       if (rb >= 0) {                                                // out-of-image cells of the region hold 0
         const float hy = 1.f - ly, hx = 1.f - lx;
         const float w00 = hy * hx, w01 = hy * lx, w10 = ly * hx, w11 = ly * lx;
-        double d00 = 0., d01 = 0., d10 = 0., d11 = 0.;
-        if (WANT_GX) {
-          d00 = (double)w00 * fx_scale;
-          d01 = (double)w01 * fx_scale;
-          d10 = (double)w10 * fx_scale;
-          d11 = (double)w11 * fx_scale;
-        }
         const int cell = cbase_lds + rb;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -506,12 +528,20 @@ __global__ __launch_bounds__(TH * 64, TH / 4) void dcn_bwd_data2_kernel(D2Args a
           gy[t] += gcm * (hx * (v10 - v00) + lx * (v11 - v01));
           gxo[t] += gcm * (hy * (v01 - v00) + ly * (v11 - v10));
           if (WANT_GX) {                                            // cells outside the image are never read back
-            const double dg = (double)gcm;
-            unsigned long long* q = &gacc[cell + r * RSZP];
-            atomicAdd(q, (unsigned long long)__double_as_longlong(fma(dg, d00, FX_MAGIC)));
-            atomicAdd(q + 1, (unsigned long long)__double_as_longlong(fma(dg, d01, FX_MAGIC)));
-            atomicAdd(q + RWD, (unsigned long long)__double_as_longlong(fma(dg, d10, FX_MAGIC)));
-            atomicAdd(q + RWD + 1, (unsigned long long)__double_as_longlong(fma(dg, d11, FX_MAGIC)));
+            cell_t* q = &gacc[cell + r * RSZP];
+            if constexpr (WIDE) {
+              const double dg = (double)gcm, ds = (double)fx_scale;
+              atomicAdd(q, (unsigned long long)__double_as_longlong(fma(dg, (double)w00 * ds, FX_MAGIC)));
+              atomicAdd(q + 1, (unsigned long long)__double_as_longlong(fma(dg, (double)w01 * ds, FX_MAGIC)));
+              atomicAdd(q + RWD, (unsigned long long)__double_as_longlong(fma(dg, (double)w10 * ds, FX_MAGIC)));
+              atomicAdd(q + RWD + 1, (unsigned long long)__double_as_longlong(fma(dg, (double)w11 * ds, FX_MAGIC)));
+            } else {
+              const float gs = gcm * fx_scale;                       // (power of two: exact)
+              atomicAdd(q, (unsigned)__float2int_rn(gs * w00));
+              atomicAdd(q + 1, (unsigned)__float2int_rn(gs * w01));
+              atomicAdd(q + RWD, (unsigned)__float2int_rn(gs * w10));
+              atomicAdd(q + RWD + 1, (unsigned)__float2int_rn(gs * w11));
+            }
           }
         }
       }
@@ -579,8 +609,10 @@ __global__ __launch_bounds__(TH * 64, TH / 4) void dcn_bwd_data2_kernel(D2Args a
         const unsigned long long tf0 = CP_T();
         (void)tf0;
         store_x();                                                  // (loads waited for at the stage barrier above)
-        if (WANT_GX && i >= 1) flush((cs0 + i - 1) * KC);
-        __syncthreads();                                            // region + emptied sums visible
+        if (WANT_GX) publish_colmax(acc);
+        if (WANT_GX && i >= 1) flush((cs0 + i - 1) * KC, fx_inv);   // (still the previous chunk's scale)
+        __syncthreads();                                            // region + emptied sums + column maxima visible
+        if (WANT_GX) derive_scale();
         CP_ACC(t_flush, tf0);
       } else {
         __builtin_amdgcn_s_waitcnt(0x0f70);                         // vmcnt(0): this chunk's weight DMA has landed
@@ -589,12 +621,14 @@ __global__ __launch_bounds__(TH * 64, TH / 4) void dcn_bwd_data2_kernel(D2Args a
         CP_ACC(t_mfma, tw0);
         const unsigned long long tf0 = CP_T();
         (void)tf0;
+        if (WANT_GX) publish_colmax(acc);
         __syncthreads();                                            // every wave has read the weight buffer
         load_x(cs0 + i);                                            // region registers live only across the flush
-        if (WANT_GX && i >= 1) flush((cs0 + i - 1) * KC);
+        if (WANT_GX && i >= 1) flush((cs0 + i - 1) * KC, fx_inv);   // (still the previous chunk's scale)
         store_x();
         if (i + 1 < n) dma_a((cs0 + i + 1) * NS, 0);                // lands during the consumption
         __syncthreads();                                            // region + emptied sums visible
+        if (WANT_GX) derive_scale();
         CP_ACC(t_flush, tf0);
       }
       const unsigned long long tw1 = CP_T();
@@ -605,7 +639,7 @@ __global__ __launch_bounds__(TH * 64, TH / 4) void dcn_bwd_data2_kernel(D2Args a
   }
   if (WANT_GX && n > 0) {
     __syncthreads();                                                // the last chunk's adds are in LDS
-    flush((cs1 - 1) * KC);
+    flush((cs1 - 1) * KC, fx_inv);
   }
 
 #ifdef CP_STAMP

@@ -68,8 +68,9 @@ class _WeightBank(object):
     behind the bank's back (load_state_dict, manual edits) simply takes the per-use path until the next refresh."""
 
     def __init__(self):
-        self.entries = {}          # (id(weight), cin, cout, code) -> [weakref, wp, version]
-        self.table = None          # (device tensor holding the job structs, njobs, total_blocks, keys in table order)
+        # (id(weight), cin, cout, code) -> [weakref, wp or None, version, data_ptr, device]; wp is allocated by refresh()
+        self.entries = {}
+        self.table = None          # per device: (device tensor holding the job structs, njobs, total_blocks, keys in table order)
 
     def get(self, weight, cin, cout, code):
         if not isinstance(weight, torch.nn.Parameter):
@@ -77,15 +78,18 @@ class _WeightBank(object):
         key = (id(weight), cin, cout, code)
         e = self.entries.get(key)
         if e is None or e[0]() is not weight:
-            taps = weight.shape[2] * weight.shape[3]
-            wp = torch.empty(_C.lib().cp_conv_mfma_weight_bytes(cin, cout, taps), dtype=torch.uint8, device=weight.device)
-            self.entries[key] = [weakref.ref(weight), wp, -1]
+            # (registration only: the buffer is allocated by the first refresh() -- a weight that is prepared once and
+            # never refreshed, e.g. at inference, does not pay for a second copy of its permuted form)
+            self.entries[key] = [weakref.ref(weight), None, -1, weight.data_ptr(), weight.device]
             self.table = None
             return None
-        return e[1] if e[2] == weight._version else None
+        # `param.data = ...`, module.to(device), load_state_dict(assign=True) or parameter flattening re-point the storage
+        # WITHOUT a version bump: the form is served only while the parameter still lives where the table read it
+        if e[1] is None or e[2] != weight._version or e[3] != weight.data_ptr() or e[4] != weight.device:
+            return None
+        return e[1]
 
     def refresh(self):
-        import ctypes
         L = _C.lib()
         dead = [k for k, e in self.entries.items() if e[0]() is None]
         for k in dead:
@@ -94,10 +98,18 @@ class _WeightBank(object):
             self.table = None
         if not self.entries:
             return
-        by_dev = {}
-        for k, e in self.entries.items():
-            by_dev.setdefault(e[1].device, []).append(k)
+        for k, e in self.entries.items():                      # storage moved (or first refresh): new buffer, new table
+            w = e[0]()
+            if e[1] is None or e[3] != w.data_ptr() or e[4] != w.device:
+                _, cin, cout, _code = k
+                e[1] = torch.empty(L.cp_conv_mfma_weight_bytes(cin, cout, w.shape[2] * w.shape[3]), dtype=torch.uint8,
+                                   device=w.device)
+                e[3], e[4] = w.data_ptr(), w.device
+                self.table = None
         if self.table is None:
+            by_dev = {}
+            for k, e in self.entries.items():
+                by_dev.setdefault(e[4], []).append(k)          # keyed on the WEIGHT's device
             self.table = {}
             for dev, keys in by_dev.items():
                 jobs = (_C.ConvPrepareJob * len(keys))()

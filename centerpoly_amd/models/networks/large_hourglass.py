@@ -211,6 +211,7 @@ class exkp(nn.Module):
                     del m.__dict__[k]          # permuted inference weights / DCN workspaces of the folded tensors
             self._heads_cat = None
             self._inter_folded = None
+        _C.release_zero_pool()                 # (gradient accumulators of the mode being left)
         return super().train(mode)
 
     def _heads_fast(self, s, cnv):
@@ -247,25 +248,27 @@ class exkp(nn.Module):
         return out
 
     def forward(self, image):
-        fused = getattr(self, "_heads_cat", None) is not None and not self.training \
-            and not torch.is_grad_enabled() and image.is_cuda
-        inter = self.pre(image)
-        outs = []
-        for s in range(self.nstack):
-            cnv = self.cnvs[s](self.kps[s](inter))
-            if fused and (cnv.shape[2] * cnv.shape[3]) % 4 == 0:
-                outs.append(self._heads_fast(s, cnv))
-            else:
-                outs.append({head: getattr(self, head)[s](cnv) for head in self.heads})
-            if s < self.nstack - 1:
-                if fused:
-                    fa, fb = self._inter_folded[s]
-                    t = _conv_folded(inter, self.inters_[s][0], fa, relu=False)
-                    inter = _conv_folded(cnv, self.cnvs_[s][0], fb, relu=True, residual=t)
+        try:
+            fused = getattr(self, "_heads_cat", None) is not None and not self.training \
+                and not torch.is_grad_enabled() and image.is_cuda
+            inter = self.pre(image)
+            outs = []
+            for s in range(self.nstack):
+                cnv = self.cnvs[s](self.kps[s](inter))
+                if fused and (cnv.shape[2] * cnv.shape[3]) % 4 == 0:
+                    outs.append(self._heads_fast(s, cnv))
                 else:
-                    inter = self.relu(self.inters_[s](inter) + self.cnvs_[s](cnv))
-                inter = self.inters[s](inter)
-        flush_batch_counts()
+                    outs.append({head: getattr(self, head)[s](cnv) for head in self.heads})
+                if s < self.nstack - 1:
+                    if fused:
+                        fa, fb = self._inter_folded[s]
+                        t = _conv_folded(inter, self.inters_[s][0], fa, relu=False)
+                        inter = _conv_folded(cnv, self.cnvs_[s][0], fb, relu=True, residual=t)
+                    else:
+                        inter = self.relu(self.inters_[s](inter) + self.cnvs_[s](cnv))
+                    inter = self.inters[s](inter)
+        finally:
+            flush_batch_counts()
         return outs
 
 

@@ -292,14 +292,21 @@ class _BnAct(torch.autograd.Function):
 
 # BatchNorm2d.num_batches_tracked of the modules that took the fused path: incremented together by ONE multi-tensor
 # launch at the end of the network's forward (flush_batch_counts) instead of ~55 four-microsecond kernels per step.
-_PENDING_BATCH_COUNTS = []
+# Flushed in a `finally` of DLASeg.forward / exkp.forward (a forward that raises part-way leaves nothing pending), at 256
+# entries, and before state_dict() of those networks; a BatchNorm that runs twice in one forward is counted twice.
+_PENDING_BATCH_COUNTS = {}         # id(buffer) -> [buffer, increments]
 
 
 def flush_batch_counts():
     if _PENDING_BATCH_COUNTS:
+        once = [t for t, n in _PENDING_BATCH_COUNTS.values() if n == 1]
+        more = [(t, n) for t, n in _PENDING_BATCH_COUNTS.values() if n != 1]
+        _PENDING_BATCH_COUNTS.clear()
         with torch.no_grad():
-            torch._foreach_add_(list(_PENDING_BATCH_COUNTS), 1)
-        del _PENDING_BATCH_COUNTS[:]
+            if once:
+                torch._foreach_add_(once, 1)
+            for t, n in more:
+                t.add_(n)
 
 
 def bn_act(bn, x, relu=True, residual=None):
@@ -308,7 +315,8 @@ def bn_act(bn, x, relu=True, residual=None):
     the plain torch modules (eval mode normally takes the folded path before getting here)."""
     if bn.training and x.is_cuda and x.dtype == torch.float32 and bn.track_running_stats \
             and bn.affine and bn.momentum is not None and x.numel() // x.shape[1] > 1:
-        _PENDING_BATCH_COUNTS.append(bn.num_batches_tracked)
+        e = _PENDING_BATCH_COUNTS.setdefault(id(bn.num_batches_tracked), [bn.num_batches_tracked, 0])
+        e[1] += 1
         if len(_PENDING_BATCH_COUNTS) >= 256:
             flush_batch_counts()
         return _BnAct.apply(x, bn.weight, bn.bias, residual, bn.running_mean, bn.running_var,
@@ -784,18 +792,25 @@ class DLASeg(nn.Module):
             for m in self.modules():
                 if hasattr(m, "_folded"):
                     m._folded = None
-                for k in [k for k in m.__dict__ if k.startswith(("_mfma_wperm", "_heads_wperm", "_heads_fused", "_dcn_fwd_ws", "_dcn_fused_ws"))]:
+                for k in [k for k in m.__dict__ if k.startswith(("_mfma_wperm", "_heads_wperm", "_heads_fused", "_dcn_fwd_ws", "_dcn_fused_ws", "_stem_wperm"))]:
                     del m.__dict__[k]          # permuted inference weights / DCN workspaces of the folded tensors
             self._heads_cat = None
+        _C.release_zero_pool()                 # (gradient accumulators of the mode being left)
         return super().train(mode)
 
+    def state_dict(self, *args, **kwargs):
+        flush_batch_counts()                   # (num_batches_tracked increments still pending from a sub-module run)
+        return super().state_dict(*args, **kwargs)
+
     def forward(self, x):
-        x = self.dla_up(self.base(x))
-        # (the reference clones these tensors, pose_dla_dcn.py:476-478; IDAUp here only re-binds list
-        #  entries and never writes into its inputs, so the copies are not needed)
-        y = [x[i] for i in range(self.last_level - self.first_level)]
-        self.ida_up(y, 0, len(y))
-        flush_batch_counts()
+        try:
+            x = self.dla_up(self.base(x))
+            # (the reference clones these tensors, pose_dla_dcn.py:476-478; IDAUp here only re-binds list
+            #  entries and never writes into its inputs, so the copies are not needed)
+            y = [x[i] for i in range(self.last_level - self.first_level)]
+            self.ida_up(y, 0, len(y))
+        finally:
+            flush_batch_counts()
         if getattr(self, "_heads_cat", None) is not None and not self.training \
                 and not torch.is_grad_enabled() and y[-1].is_cuda \
                 and (y[-1].shape[2] * y[-1].shape[3]) % 4 == 0:

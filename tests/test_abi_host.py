@@ -48,7 +48,8 @@ def test_graft_entry_build_and_header_version_agree():
 def test_argument_validation_without_gpu():
     """Entry points validate before touching the device: callable with no GPU."""
     L = _C.lib()
-    assert L.cp_polydet_decode_workspace_bytes(1, 8, 256, 512, 128) == 256 * 128 * 8
+    # 256 tiles x K keys of 8 bytes + the merge level's 8 lists of K keys
+    assert L.cp_polydet_decode_workspace_bytes(1, 8, 256, 512, 128) == (256 + 8) * 128 * 8
     assert L.cp_polydet_decode(None, None, None, None, 1, 8, 4, 4, 32, 8, 0, None, None, None,
                                None, 0, None) == -1
     assert L.cp_sigmoid_focal_forward(None, None, 16, None, None, None, 0, None) == -1

@@ -107,20 +107,25 @@ def test_linearity_in_grad_out_full_size(shape):
             assert (d - 2.0 * a).abs().max().item() <= 1e-5 * scale, name
 
 
+@pytest.mark.parametrize("exact", [False, True], ids=["split_bf16", "exact_f32"])
 @pytest.mark.parametrize("shape", [FULL_SHAPES[0], FULL_SHAPES[2]], ids=[IDS[0], IDS[2]])
-def test_batch_split_equality_and_determinism_full_size(shape):
+def test_batch_split_equality_and_determinism_full_size(shape, exact):
     B = shape[0]
+    flags = _C.DCN_BWD_EXACT_F32 if exact else 0
     x, om, w, go = _inputs("split", *shape, clip=1.9)     # every tap stays inside the LDS region
-    gx, gom, gw, gb = _backward(x, om, w, go)
-    gx2, gom2, _, _ = _backward(x, om, w, go, want=("x", "om"))
+    gx, gom, gw, gb = _backward(x, om, w, go, flags=flags)
+    gx2, gom2, _, _ = _backward(x, om, w, go, want=("x", "om"), flags=flags)
     assert torch.equal(gx, gx2) and torch.equal(gom, gom2), "data gradients differ between two runs"
+    # a one-image launch may use another tile height and split the input channels over more workgroups than the batched
+    # one (grid filling): the per-tile, per-chunk fixed-point scale and the order in which the partial sums (grad_x slabs,
+    # grad_offset / grad_mask partials) meet then differ.  grad_x is a sum of fixed-point contributions, each rounded to
+    # 2^-21 of the chunk's largest |grad column| (32-bit cells, round 4: ~1e-5 of max|grad_x| after ~36 adds), or to 2^-36
+    # of it with the exact-f32 arithmetic (64-bit cells: below the fp32 rounding of the result)
+    tol_x = 2e-6 if exact else 3e-5
     gw_sum = torch.zeros_like(gw)
     for b in range(B):
-        sx, som, sw, _ = _backward(x[b:b + 1].contiguous(), om[b:b + 1].contiguous(), w, go[b:b + 1].contiguous())
-        # a one-image launch may use another tile height and split the input channels over more workgroups
-        # than the batched one (grid filling): the per-tile fixed-point scale and the order in which the
-        # partial sums (grad_x slabs, grad_offset / grad_mask partials) meet then differ in the last bits
-        assert (sx[0] - gx[b]).abs().max().item() <= 2e-6 * gx[b].abs().max().item(), \
+        sx, som, sw, _ = _backward(x[b:b + 1].contiguous(), om[b:b + 1].contiguous(), w, go[b:b + 1].contiguous(), flags=flags)
+        assert (sx[0] - gx[b]).abs().max().item() <= tol_x * gx[b].abs().max().item(), \
             "grad_x of image %d depends on the batch" % b
         assert (som[0] - gom[b]).abs().max().item() <= 1e-5 * gom[b].abs().max().item(), \
             "grad_offset/mask of image %d depends on the batch" % b
