@@ -583,7 +583,17 @@ size_t wperm_bytes(const cp_dcn_shape* s) {
 // maps keep the gather kernels with their K split.
 bool region_pays(const cp_dcn_shape* s) {
   const long long wgs = (long long)((s->H + 7) / 8) * ((s->W + 31) / 32) * ((s->Cout + 63) / 64) * s->B;
-  return wgs >= 256 || (wgs >= 128 && s->Cin <= 128);       // (deep, small maps: the gather kernels' K split fills the chip better)
+  if (wgs >= 256 || (wgs >= 128 && s->Cin <= 128)) return true;
+  // round 4: deep, small maps take the region kernel with its input channels split over grid z (>= 256 workgroups of >= 2
+  // chunks); before, they kept the gather kernels (256->256 @64x128: 89 us there)
+  return wgs * cp_dcn_region_ksplit(s) >= 256;
+}
+
+// slices of the region kernel's K split for this shape (1 = none)
+int region_ksplit(const cp_dcn_shape* s) {
+  const long long wgs = (long long)((s->H + 7) / 8) * ((s->W + 31) / 32) * ((s->Cout + 63) / 64) * s->B;
+  if (wgs >= 256) return 1;                                 // (128 .. 255 workgroups: half the CUs would hold one, or none)
+  return cp_dcn_region_ksplit(s);
 }
 
 template <int BN, int WPS>
@@ -613,7 +623,11 @@ extern "C" size_t cp_dcn_v2_forward_workspace_bytes(const cp_dcn_shape* s) {
   if (Ho <= 0 || Wo <= 0) return 0;
   const Plan p = make_plan(s->B, s->Cin, s->Cout, Ho * Wo);
   // [permuted weights of the split-bf16 contraction | K-split partial sums]
-  const size_t part = p.splitk <= 1 ? 0 : (size_t)p.splitk * s->B * s->Cout * Ho * Wo * sizeof(float);
+  size_t part = p.splitk <= 1 ? 0 : (size_t)p.splitk * s->B * s->Cout * Ho * Wo * sizeof(float);
+  if (cp_dcn_region_supported(s)) {
+    const size_t rp = region_ksplit(s) <= 1 ? 0 : (size_t)region_ksplit(s) * s->B * s->Cout * Ho * Wo * sizeof(float);
+    if (rp > part) part = rp;
+  }
   return wperm_bytes(s) + part;
 }
 
@@ -656,8 +670,19 @@ extern "C" int cp_dcn_v2_forward(const cp_dcn_shape* s, const float* x, const fl
       const int rc = cp_dcn_region_prepare(s, weight, workspace, st);
       if (rc != CP_OK) return rc;
     }
-    return cp_dcn_region_forward(s, x, offset, offset_bstride, mask, mask_bstride, mask_is_logit, workspace, bias,
-                                 ep_scale, ep_shift, relu, out, nullptr, nullptr, nullptr, st);
+    const int ks = region_ksplit(s);
+    float* partial = ks > 1 ? (float*)((char*)workspace + wpb) : nullptr;
+    const int rc = cp_dcn_region_forward(s, x, offset, offset_bstride, mask, mask_bstride, mask_is_logit, workspace, bias,
+                                         ep_scale, ep_shift, relu, out, nullptr, nullptr, nullptr, partial, ks, st);
+    if (rc != CP_OK || ks <= 1) return rc;
+    DcnFwdArgs ra;                                          // the slices' raw sums -> out, + bias / folded BN / ReLU
+    ra.partial = partial; ra.out = out; ra.bias = bias; ra.ep_scale = ep_scale; ra.ep_shift = ep_shift; ra.relu = relu;
+    ra.B = s->B; ra.Ho = Ho; ra.Wo = Wo; ra.Cout = s->Cout; ra.splitk = ks;
+    const long long n_per_b = (long long)s->Cout * Ho * Wo;
+    long long nb = ((long long)s->B * n_per_b + 255) / 256;
+    if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(dcn_splitk_reduce_kernel, dim3((unsigned)nb), dim3(256), 0, st, ra, n_per_b);
+    return cp_launch_status();
   }
   if (p.splitk > 1 || bf) {
     if (!workspace || workspace_bytes < cp_dcn_v2_forward_workspace_bytes(s)) return CP_EWORKSPACE;
@@ -701,7 +726,10 @@ static size_t fused_region_bytes(const cp_dcn_shape* s) { return cp_align_up(cp_
 // at most 64 input channels: measured at 128 -> 64 @128x256 the in-kernel pass (8 chunks on 128 workgroups, 81 us in
 // all) does not beat the stand-alone convolution with its K split (58 + 20 us); at 64 -> 64 @256x512 it does (64 vs 89).
 extern "C" int cp_dcn_v2_forward_fused_supported(const cp_dcn_shape* s) {
-  return s && s->B > 0 && s->Cout > 0 && s->Cout <= 64 && s->Cin <= 64 && cp_dcn_region_supported(s) && region_pays(s) ? 1 : 0;
+  return s && s->B > 0 && s->Cout > 0 && s->Cout <= 64 && s->Cin <= 64 && cp_dcn_region_supported(s) && region_pays(s) &&
+                 region_ksplit(s) == 1
+             ? 1
+             : 0;                                 // (the fused form never splits its input channels)
 }
 
 extern "C" size_t cp_dcn_v2_forward_fused_workspace_bytes(const cp_dcn_shape* s) {
@@ -725,5 +753,5 @@ extern "C" int cp_dcn_v2_forward_fused(const cp_dcn_shape* s, const float* x, co
     if (rc != CP_OK) return rc;
   }
   return cp_dcn_region_forward(s, x, nullptr, 0, nullptr, 0, 1, workspace, bias, ep_scale, ep_shift, relu, out, om_wp, om_bias,
-                               om_out, st);
+                               om_out, nullptr, 1, st);
 }

@@ -84,6 +84,11 @@ struct RegionArgs {
   const bf16x8* om_wp;
   const float* om_bias;
   float* om_out;
+  // K split (deep, small maps whose tiles do not fill the chip): grid z = B * ksplit, slice z / B takes the input-channel
+  // chunks [slice * chunks_per_split, ...) and writes its RAW partial sums to partial[slice][B][Cout][H][W]; the caller
+  // adds them up and applies bias / folded BN / ReLU (dcn_splitk_reduce_kernel of dcn_fwd.hip).  ksplit = 1: off.
+  float* partial;
+  int ksplit, chunks_per_split;
 };
 
 // wp[(((cb * nchunk + chunk) * 9 + t) * 4 + ct * 2 + hl) * 64 + lane][j] =
@@ -185,8 +190,11 @@ __global__ __launch_bounds__(256, 2) void dcn_fwd_region_kernel(RegionArgs a) {
   int tile = blockIdx.x;
   if ((ntile & 7) == 0) tile = (tile & 7) * (ntile >> 3) + (tile >> 3);
   const int ty = (tile / a.tiles_x) * TH, tx = (tile % a.tiles_x) * TW;
-  const int b = blockIdx.z, cb = blockIdx.y;
-  const int nchunk = a.Cin >> 4;
+  const int b = (int)blockIdx.z % a.B, ksl = (int)blockIdx.z / a.B, cb = blockIdx.y;
+  const int nchunk_all = a.Cin >> 4;
+  const int c_begin = FUSE ? 0 : ksl * a.chunks_per_split;                     // (the fused form never splits)
+  const int c_end = FUSE ? nchunk_all : min(nchunk_all, c_begin + a.chunks_per_split);
+  const int nchunk = nchunk_all;                                               // (weight layout / the fused offset conv)
   const unsigned plane_bytes = (unsigned)HW * 4u;
 
   // Buffer descriptors span the whole tensor of the image; a channel plane rides in the scalar offset.  (Measured on
@@ -468,7 +476,7 @@ __global__ __launch_bounds__(256, 2) void dcn_fwd_region_kernel(RegionArgs a) {
   for (int i0 = 0; i0 < ITEMS; i0 += 5) {
     f32x4 sv[5];
 #pragma unroll
-    for (int i = 0; i < 5; ++i) stage_load(i0 + i, 0, sv[i]);
+    for (int i = 0; i < 5; ++i) stage_load(i0 + i, c_begin * 16, sv[i]);
 #pragma unroll
     for (int i = 0; i < 5; ++i) stage_store(i0 + i, 0u, sv[i]);
   }
@@ -484,7 +492,7 @@ __global__ __launch_bounds__(256, 2) void dcn_fwd_region_kernel(RegionArgs a) {
   const bf16x8* wq = a.wp + (long long)cb * nchunk * (TAPS * 4 * 64) + lane;
   bf16x8 wf[4];
 #pragma unroll
-  for (int f = 0; f < 4; ++f) wf[f] = wq[f * 64];
+  for (int f = 0; f < 4; ++f) wf[f] = wq[(long long)c_begin * TAPS * (4 * 64) + f * 64];
   __syncthreads();
   RSTAMP(3);
 
@@ -492,7 +500,7 @@ __global__ __launch_bounds__(256, 2) void dcn_fwd_region_kernel(RegionArgs a) {
 #if CP_RPRIO
   const int prio_half = (int)((blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) >> 8);
 #endif
-  for (int c = 0; c < nchunk; ++c) {
+  for (int c = c_begin; c < c_end; ++c) {
 #if CP_RPRIO
     // The two workgroups of a CU share its SIMDs; VALU issue goes to the older wave, so one of them finishes its K loop
     // ~25 % later than the other and the launch waits for it.  Alternating the priority per chunk between the halves of
@@ -502,9 +510,9 @@ __global__ __launch_bounds__(256, 2) void dcn_fwd_region_kernel(RegionArgs a) {
     if (((prio_half) ^ c) & 1) __builtin_amdgcn_s_setprio(1);
     else __builtin_amdgcn_s_setprio(0);
 #endif
-    const unsigned cur = (unsigned)(c & 1) * CHB, nxt = CHB - cur;
+    const unsigned cur = (unsigned)((c - c_begin) & 1) * CHB, nxt = CHB - cur;
     const unsigned curk = cur + kgoff;
-    const bool more = c + 1 < nchunk;
+    const bool more = c + 1 < c_end;
     const int cn = (c + 1) * 16;
     f32x4 sv[3];
 #pragma unroll
@@ -633,8 +641,11 @@ __global__ __launch_bounds__(256, 2) void dcn_fwd_region_kernel(RegionArgs a) {
         const float sc = a.ep_scale ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_sc, cbase + (unsigned)col * 4u, 0, 0)) : 1.f;
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
-          float o = acc[r][ct][i] * sc + sh;
-          if (a.relu) o = fmaxf(o, 0.f);
+          float o = acc[r][ct][i];
+          if (a.ksplit <= 1) {                              // (a slice of a K split leaves its raw sums)
+            o = o * sc + sh;
+            if (a.relu) o = fmaxf(o, 0.f);
+          }
           ot[((col + 4 * kg) * 2 + r) * 32 + px] = o;
         }
       }
@@ -645,8 +656,9 @@ __global__ __launch_bounds__(256, 2) void dcn_fwd_region_kernel(RegionArgs a) {
                       (long long)a.Cout * HW * 4 < (1ll << 31);
     const int r = (lane >> 3) & 1, x4 = tx + (lane & 7) * 4, y = ty + 2 * wid + r;
     const int col0 = lane >> 4;                                // + 4 it
+    float* const outp = a.ksplit > 1 ? a.partial + (long long)ksl * a.B * a.Cout * HW : a.out;
     if (wide) {
-      float* ob = a.out + (long long)b * a.Cout * HW;
+      float* ob = outp + (long long)b * a.Cout * HW;
       const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc(ob, 0, (int)((unsigned)a.Cout * plane_bytes), 0x00020000);
       const unsigned vo = (y < H && x4 < W) ? ((unsigned)(cb * 64 + col0) * (unsigned)HW + (unsigned)(y * W + x4)) * 4u : OOB;
 #pragma unroll
@@ -660,7 +672,7 @@ __global__ __launch_bounds__(256, 2) void dcn_fwd_region_kernel(RegionArgs a) {
         const int co = cb * 64 + col0 + it * 4;
         const f32x4 v = *reinterpret_cast<const f32x4*>(ot + (it * 8 + (lane >> 3)) * 32 + (lane & 7) * 4);
         if (co >= a.Cout || y >= H) continue;
-        float* dst = a.out + (((long long)b * a.Cout + co) * H + y) * W + x4;
+        float* dst = outp + (((long long)b * a.Cout + co) * H + y) * W + x4;
 #pragma unroll
         for (int j = 0; j < 4; ++j)
           if (x4 + j < W) dst[j] = v[j];
@@ -714,10 +726,25 @@ int cp_dcn_region_prepare_om(const cp_dcn_shape* s, const float* om_weight, void
 
 // om_wp != null: the fused form (conv_offset_mask computed in the kernel from om_wp / om_bias; offset / mask unused,
 // om_out optional)
+int cp_dcn_region_ksplit(const cp_dcn_shape* s) {
+  // Tiles x 64-channel blocks x images that do not give every CU its two workgroups are topped up by splitting the
+  // input channels: >= 2 chunks of 16 per slice, about 512 workgroups.
+  const long long wgs = (long long)((s->H + TH - 1) / TH) * ((s->W + TW - 1) / TW) * ((s->Cout + 63) / 64) * s->B;
+  const int nchunk = s->Cin / 16;
+  if (wgs >= 384 || nchunk < 4) return 1;
+  int k = (int)((512 + wgs - 1) / wgs);
+  if (k > nchunk / 2) k = nchunk / 2;
+  if (k > 16) k = 16;
+  if (k < 1) k = 1;
+  const int cps = (nchunk + k - 1) / k;
+  return (nchunk + cps - 1) / cps;
+}
+
 int cp_dcn_region_forward(const cp_dcn_shape* s, const float* x, const float* offset, int64_t offset_bstride,
                           const float* mask, int64_t mask_bstride, int32_t mask_is_logit, const void* wp,
                           const float* bias, const float* ep_scale, const float* ep_shift, int32_t relu, float* out,
-                          const void* om_wp, const float* om_bias, float* om_out, hipStream_t st) {
+                          const void* om_wp, const float* om_bias, float* om_out, float* partial, int ksplit,
+                          hipStream_t st) {
   RegionArgs a;
   a.x = x; a.offset = offset; a.mask = mask; a.wp = (const bf16x8*)wp; a.bias = bias;
   a.ep_scale = ep_scale; a.ep_shift = ep_shift; a.out = out;
@@ -727,8 +754,14 @@ int cp_dcn_region_forward(const cp_dcn_shape* s, const float* x, const float* of
   a.tiles_x = (s->W + TW - 1) / TW;
   a.tiles_y = (s->H + TH - 1) / TH;
   a.om_wp = (const bf16x8*)om_wp; a.om_bias = om_bias; a.om_out = om_out;
+  if (ksplit < 1 || (ksplit > 1 && (!partial || om_wp))) return CP_EINVAL;
+  const int nchunk = s->Cin / 16;
+  a.partial = partial;
+  a.chunks_per_split = (nchunk + ksplit - 1) / ksplit;
+  a.ksplit = (nchunk + a.chunks_per_split - 1) / a.chunks_per_split;
+  if ((long long)s->B * a.ksplit > 65535) return CP_EUNSUPPORTED;
   const int lds = 2 * CHB;
-  dim3 grid(a.tiles_x * a.tiles_y, (s->Cout + 63) / 64, s->B);
+  dim3 grid(a.tiles_x * a.tiles_y, (s->Cout + 63) / 64, s->B * a.ksplit);
   if (om_wp) {
     a.mask_is_logit = 1;                    // the convolution's mask channels are logits
     (void)hipFuncSetAttribute((const void*)dcn_fwd_region_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);

@@ -26,8 +26,10 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 TOL = 2e-5          # of the output's max-norm: split-bf16 x3 measures 3e-6, exact f32 3e-7
 
-# (Cin, Cout, H, W): config 2's launches that run the region kernel
-SHAPES = [(64, 64, 256, 512), (128, 128, 128, 256), (128, 64, 128, 256)]
+# (Cin, Cout, H, W): config 2's launches that run the region kernel -- the last four (deep, small maps) with their input
+# channels split over grid z and the slices' partial sums reduced by a second launch (round 4)
+SHAPES = [(64, 64, 256, 512), (128, 128, 128, 256), (128, 64, 128, 256), (256, 256, 64, 128), (256, 128, 64, 128),
+          (512, 256, 32, 64), (256, 64, 64, 128)]
 IDS = ["%d-%d@%dx%d" % s for s in SHAPES]
 
 
