@@ -592,8 +592,9 @@ bool region_pays(const cp_dcn_shape* s) {
 // slices of the region kernel's K split for this shape (1 = none)
 int region_ksplit(const cp_dcn_shape* s) {
   const long long wgs = (long long)((s->H + 7) / 8) * ((s->W + 31) / 32) * ((s->Cout + 63) / 64) * s->B;
-  if (wgs >= 256) return 1;                                 // (128 .. 255 workgroups: half the CUs would hold one, or none)
-  return cp_dcn_region_ksplit(s);
+  if (wgs >= 256) return 1;
+  if (wgs >= 128 && s->Cin <= 64) return 1;                 // (4 chunks: the fused module launch is worth more than a split)
+  return cp_dcn_region_ksplit(s);                           // 128 .. 255 workgroups leave half the CUs with one, or none
 }
 
 template <int BN, int WPS>
