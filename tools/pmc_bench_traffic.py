@@ -14,7 +14,9 @@ import bench
 # (B, Cin, Cout, H, W) of the DLA-34 DCN layers at 2048x1024 by launch grid (threads).  Region kernel
 # (dcn_fwd_region.hip): 256 threads per 8 x 32 pixel tile and 64-channel block -> 64->64 @256x512 = 512 workgroups;
 # the gather kernels' 524288-thread grid (256 threads per 64-pixel tile) is kept for the exact-f32 arithmetic
-SHAPES = {131072: (1, 64, 64, 256, 512), 524288: (1, 64, 64, 256, 512)}
+# (round 4: other region launches -- the K-split ones, grid (32768, 1, 4) -- have the same thread count as the fused module
+# launch: the kernel NAME tells them apart, `<true>` = the fused form)
+SHAPES = {("dcn_fwd_region_kernel<true>", 131072): (1, 64, 64, 256, 512), ("dcn_fwd_pipe", 524288): (1, 64, 64, 256, 512)}
 
 
 # the dominant launch shape of the split-bf16 3x3 convolution at inference (bench.py's roofline_conv3x3):
@@ -33,9 +35,9 @@ def avg(dirname, counter, match="dcn_fwd"):
     return {g: (sum(v) / len(v), len(v)) for g, v in vals.items()}
 
 
-fetch, write = avg(sys.argv[1], "FETCH_SIZE"), avg(sys.argv[2], "WRITE_SIZE")
 layers, raw = {}, {}
-for grid, shape in SHAPES.items():
+for (kern, grid), shape in SHAPES.items():
+    fetch, write = avg(sys.argv[1], "FETCH_SIZE", kern), avg(sys.argv[2], "WRITE_SIZE", kern)
     if grid in fetch and grid in write:
         f, n = fetch[grid]
         w, _ = write[grid]
