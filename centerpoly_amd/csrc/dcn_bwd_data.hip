@@ -200,7 +200,10 @@ __global__ __launch_bounds__(TH * 64, TH / 4) void dcn_bwd_data2_kernel(D2Args a
   constexpr bool DBUF = TH <= 8;
   static_assert(DBUF || NS == 1, "the single-buffer schedule is written for one slab per chunk");
   __shared__ f32x4 Abuf[DBUF ? 2 : 1][A_F4];               // weights of one (chunk, slab), fragment order
-  __shared__ float xreg[KC * RSZP];                        // input region of the chunk's channels
+  // input region of the chunk's channels, channel-interleaved in groups of four ([group][cell] float4, round 4): a lane
+  // (pixel, channels 4g .. 4g+3) reads a corner of its four channels with ONE ds_read_b128 -- four reads per tap where
+  // the planar layout of rounds 2-3 took sixteen ds_read_b32; 16 consecutive lanes = 16 neighbouring cells = 256 bytes
+  __shared__ __attribute__((aligned(16))) f32x4 xreg[(KC / 4) * RSZ];
   constexpr bool WIDE = !BF;                               // 64-bit cells under the exact-f32 arithmetic
   using cell_t = typename std::conditional<WIDE, unsigned long long, unsigned>::type;
   __shared__ __attribute__((aligned(16))) cell_t gacc[WANT_GX ? KC * RSZP : 4];   // fixed-point grad_x region sums
@@ -371,20 +374,22 @@ __global__ __launch_bounds__(TH * 64, TH / 4) void dcn_bwd_data2_kernel(D2Args a
     }
   };
   constexpr int NXT = NTHR;                                         // threads that stage the input region
-  constexpr int XRX = (KC * RSZ + NXT - 1) / NXT;                   // region cells per X thread
-  float xr[XRX];
+  constexpr int XRX = ((KC / 4) * RSZ + NXT - 1) / NXT;             // (group, cell) float4 items per X thread
+  f32x4 xr[XRX];
   auto load_x = [&](int ch) {                                       // X waves only
     const unsigned cbase = (unsigned)(ch * KC) * plane_bytes;       // rides in voffset (range-checked);
 #pragma unroll                                                      // OOB + cbase stays past the tensor
     for (int i = 0; i < XRX; ++i) {
       int e = tid + NXT * i;
       asm volatile("" : "+v"(e));                                   // keep the index math out of the loop-invariant set
-      const int c = e / RSZ, cell = e - c * RSZ;
+      const int gq = e / RSZ, cell = e - gq * RSZ;
       const int ry = cell / RWD, rx = cell - ry * RWD;
       const int gy_ = ry0 + ry, gx_ = rx0 + rx;
-      const bool ok = e < KC * RSZ && gy_ >= 0 && gy_ < a.H && gx_ >= 0 && gx_ < a.W;
-      const unsigned off = ok ? (unsigned)c * plane_bytes + 4u * (unsigned)(gy_ * a.W + gx_) : OOB;
-      xr[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_x, off + cbase, 0, 0));
+      const bool ok = e < (KC / 4) * RSZ && gy_ >= 0 && gy_ < a.H && gx_ >= 0 && gx_ < a.W;
+      const unsigned off = ok ? (unsigned)(4 * gq) * plane_bytes + 4u * (unsigned)(gy_ * a.W + gx_) : OOB;
+#pragma unroll
+      for (int q = 0; q < 4; ++q)                                   // (everything in voffset: the range check covers channels past Cin)
+        xr[i][q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_x, off + cbase + (unsigned)q * plane_bytes, 0, 0));
     }
   };
   auto store_x = [&]() {                                            // X waves only
@@ -392,8 +397,7 @@ __global__ __launch_bounds__(TH * 64, TH / 4) void dcn_bwd_data2_kernel(D2Args a
     for (int i = 0; i < XRX; ++i) {
       int e = tid + NXT * i;
       asm volatile("" : "+v"(e));
-      const int c = e / RSZ;
-      if (e < KC * RSZ) xreg[c * RSZP + (e - c * RSZ)] = xr[i];
+      if (e < (KC / 4) * RSZ) xreg[e] = xr[i];
     }
   };
 
@@ -495,24 +499,21 @@ __global__ __launch_bounds__(TH * 64, TH / 4) void dcn_bwd_data2_kernel(D2Args a
 #pragma unroll
     for (int t = T0; t < T1; ++t) rbs[t - T0] = __float_as_int(rec[t * NPX + wpx].w);
     float4 rcb[2];                                                  // recipe and corners of taps t (slot t & 1) and t+1
-    float vb_[2][4][4];
+    f32x4 vc_[2][4];                                                // corners 00, 01, 10, 11 x the lane's four channels
     auto fetch = [&](int t, int slot) __attribute__((always_inline)) {
       rcb[slot] = rec[t * NPX + wpx];
-      const int rbc = max(rbs[t - T0], 0) + cbase_lds;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        vb_[slot][r][0] = xreg[rbc + r * RSZP];
-        vb_[slot][r][1] = xreg[rbc + r * RSZP + 1];
-        vb_[slot][r][2] = xreg[rbc + r * RSZP + RWD];
-        vb_[slot][r][3] = xreg[rbc + r * RSZP + RWD + 1];
-      }
+      const int rbc = max(rbs[t - T0], 0) + g * RSZ;
+      vc_[slot][0] = xreg[rbc];
+      vc_[slot][1] = xreg[rbc + 1];
+      vc_[slot][2] = xreg[rbc + RWD];
+      vc_[slot][3] = xreg[rbc + RWD + 1];
     };
     fetch(T0, T0 & 1);
 #pragma unroll
     for (int t = T0; t < T1; ++t) {
       const float ly = rcb[t & 1].x, lx = rcb[t & 1].y, m = rcb[t & 1].z;
       const int rb = rbs[t - T0];
-      const float (&v)[4][4] = vb_[t & 1];
+      const f32x4 (&vc)[4] = vc_[t & 1];
       if (t + 1 < T1) fetch(t + 1, (t + 1) & 1);
       __builtin_amdgcn_sched_barrier(0);                            // keep those reads ahead of the adds below
       if (rb >= 0) {                                                // out-of-image cells of the region hold 0
@@ -522,11 +523,15 @@ __global__ __launch_bounds__(TH * 64, TH / 4) void dcn_bwd_data2_kernel(D2Args a
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float gc = acc[t][r];
-          const float v00 = v[r][0], v01 = v[r][1], v10 = v[r][2], v11 = v[r][3];
-          gm[t] += gc * (w00 * v00 + w01 * v01 + w10 * v10 + w11 * v11);
+          const float v00 = vc[0][r], v01 = vc[1][r], v10 = vc[2][r], v11 = vc[3][r];
+          // d/dy and d/dx of the bilinear interpolant, and the interpolant itself from them (14 operations where the
+          // three separate corner forms took 16): val = v00 + lx (v01 - v00) + ly (hx (v10 - v00) + lx (v11 - v01))
+          const float dyv = hx * (v10 - v00) + lx * (v11 - v01);
+          const float dxv = hy * (v01 - v00) + ly * (v11 - v10);
+          gm[t] += gc * fmaf(ly, dyv, fmaf(lx, v01 - v00, v00));
           const float gcm = gc * m;
-          gy[t] += gcm * (hx * (v10 - v00) + lx * (v11 - v01));
-          gxo[t] += gcm * (hy * (v01 - v00) + ly * (v11 - v10));
+          gy[t] += gcm * dyv;
+          gxo[t] += gcm * dxv;
           if (WANT_GX) {                                            // cells outside the image are never read back
             cell_t* q = &gacc[cell + r * RSZP];
             if constexpr (WIDE) {
