@@ -93,6 +93,19 @@ def test_decode_full_size_config2():
     assert keys.unique().numel() == 128
 
 
+@pytest.mark.parametrize("C,H,W,K", [(40, 128, 256, 128), (3, 96, 160, 256), (80, 64, 512, 100)],
+                         ids=["40cls-two-merge-levels", "K256", "80cls-K100"])
+def test_decode_many_classes_and_merge_levels(C, H, W, K):
+    """Round-4 decode: more than 32 tiles x K candidates need the parallel merge stage, more than 32 x 32 tiles need it
+    twice (the lists ping-pong between the two workspace halves); K = 256 is the kernel's maximum (one winner per
+    thread of the last stage); K = 100 does not divide the 4096-key segments evenly.  Dense white-noise heat: every tile
+    holds more than K local maxima, so no zero-valued key survives -- plus a copy with a plateau of equal scores."""
+    heat = torch.sigmoid(T(synth.normal("manycls/hm%d" % C, (2, C, H, W))))
+    heat[1, C // 2, 10:20, 30:60] = 0.999                     # ties that straddle the cut: the index passes run
+    ref, rinds, rcls, dets, inds, clses = _decode_both(heat, N=4, K=K)
+    assert torch.equal(inds, rinds) and torch.equal(clses, rcls) and torch.equal(dets, ref)
+
+
 def test_decode_rejects_bad_arguments():
     from centerpoly_amd.models.decode import polydet_decode
     heat = torch.rand(1, 2, 8, 8, device=DEV)
