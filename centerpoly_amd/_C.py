@@ -79,6 +79,7 @@ _SIGNATURES = {
     "cp_conv_direct_wgrad_supported": (c_int32, [c_int32] * 5),
     "cp_conv_direct_wgrad": (c_int32, [_P, _P, _P] + [c_int32] * 8 + [_P]),
     "cp_conv_direct_forward": (c_int32, [_P, _P, _P, _P] + [c_int32] * 9 + [_P]),
+    "cp_conv_direct_forward_ex": (c_int32, [_P, _P, _P, _P] + [c_int32] * 10 + [_P]),
     "cp_conv3x3_mfma_supported": (c_int32, [c_int32] * 4),
     "cp_conv3x3_mfma_weight_bytes": (c_size_t, [c_int32] * 2),
     "cp_conv3x3_mfma_prepare": (c_int32, [_P, c_int32, c_int32, c_int32, _P, _P]),

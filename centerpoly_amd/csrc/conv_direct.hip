@@ -154,6 +154,181 @@ __global__ __launch_bounds__(256) void conv3x3_c16_kernel(ConvArgs a) {
   }
 }
 
+// ------------------------------------------- 3x3, 16 input channels, split-bf16 x3 (round 4) ---
+// The same layers on the bf16 matrix cores (the arithmetic of conv_mfma.hip: a * b ~ ah*bh + ah*bl + al*bh, fp32
+// accumulate, ~2^-16 per product).  The exact kernel above sits on the f32 matrix pipe (level0: 104 us against 61 at
+// that pipe's peak); three v_mfma_f32_16x16x32_bf16 per 32 k-values are a fifth of its matrix time, which leaves the
+// layers at their memory traffic.  K = tap * 16 + ci, 144 padded to 160 = five k-steps of two taps x 16 channels: lane
+// (pixel lane & 15, group g = lane >> 4) supplies the 8 channels 8 (g & 1) .. of tap 2 s + (g >> 1) -- ONE ds_read_b128
+// per half (hi / lo) from a halo tile staged as [hi | lo][channel half][cell][8 x bf16] (16 lanes of a group read 16
+// neighbouring cells: 256 contiguous bytes at stride 1).  Weights: split once into the wave's registers (A fragments).
+// D as above: pixel on the lane, four output channels in the accumulator registers.
+typedef __bf16 cbf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 cbf16x2 __attribute__((ext_vector_type(2)));
+typedef float cf32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned cu32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void csplit2(float v0, float v1, unsigned& hi, unsigned& lo) {
+  const cbf16x2 h = __builtin_convertvector(cf32x2{v0, v1}, cbf16x2);
+  const unsigned hb = __builtin_bit_cast(unsigned, h);
+  const float h0 = __builtin_bit_cast(float, hb << 16), h1 = __builtin_bit_cast(float, hb & 0xffff0000u);
+  const cbf16x2 l = __builtin_convertvector(cf32x2{v0 - h0, v1 - h1}, cbf16x2);
+  hi = hb;
+  lo = __builtin_bit_cast(unsigned, l);
+}
+
+template <int COUT, int STRIDE>
+__global__ __launch_bounds__(256) void conv3x3_c16_bf16_kernel(ConvArgs a) {
+  constexpr int CIN = 16, MT = COUT / 16, KS = 5;                    // five k-steps of 32 (taps 2 s, 2 s + 1; tap 9 = padding)
+  constexpr int TH = STRIDE == 1 ? 8 : 4, TW = 64;                   // output tile
+  constexpr int IH = (TH - 1) * STRIDE + 3;
+  constexpr int NC4 = ((TW - 1) * STRIDE + 3 + 3 + 3) / 4;           // float4 chunks per tile row (from column -4)
+  constexpr int IW = 4 * NC4;                                        // cells per tile row
+  constexpr int CELLS = IH * IW;
+  constexpr int HALF = CELLS * 16;                                   // bytes of one (hi | lo, channel half) plane
+  __shared__ __attribute__((aligned(16))) unsigned char xs[4 * HALF];   // [hi | lo][half][cell][8 bf16]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lpx = lane & 15, g = lane >> 4;
+  const int b = blockIdx.z;
+  const int oy0 = blockIdx.y * TH, ox0 = blockIdx.x * TW;
+  const int iy0 = oy0 * STRIDE - 1;
+  const int HW = a.H * a.W;
+
+  // weights -> registers: A[co = 16 m + lpx][k = 32 s + 8 g + j] = W[co][ci = 8 (g & 1) + j][tap = 2 s + (g >> 1)]
+  cbf16x8 wh[MT][KS], wl[MT][KS];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int s_ = 0; s_ < KS; ++s_) {
+      const int tap = 2 * s_ + (g >> 1);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float v = tap < 9 ? a.w[((16 * m + lpx) * CIN + 8 * (g & 1) + j) * 9 + tap] : 0.f;
+        const __bf16 h = (__bf16)v;
+        wh[m][s_][j] = h;
+        wl[m][s_][j] = (__bf16)(v - (float)h);
+      }
+    }
+  // per-lane byte offset of the lane's tap in k-step s (tile cell of tap (ky, kx) relative to the output pixel's cell)
+  int toff[KS];
+#pragma unroll
+  for (int s_ = 0; s_ < KS; ++s_) {
+    const int tap = min(2 * s_ + (g >> 1), 8);                       // (the padding tap multiplies zero weights)
+    toff[s_] = ((tap / 3) * IW + (tap % 3)) * 16 + (g & 1) * HALF;
+  }
+
+  // stage the halo tile: one item = (channel half, row, float4 chunk): 8 channels x 4 pixels -> 4 cells x (hi, lo)
+  const float* xb = a.x + (long long)b * CIN * HW;
+  const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(xb), 0, (int)((unsigned)CIN * (unsigned)HW * 4u), 0x00020000);
+  const int gx0 = ox0 * STRIDE - 4;                                  // tap column kx sits at tile column 3 + kx
+  const bool vec = (a.W & 3) == 0;
+  constexpr int NITEM = 2 * IH * NC4, NI = (NITEM + 255) / 256;
+  if (vec) {
+    // every load of the thread's items in flight before the first split (one memory latency per workgroup, not NI)
+    f32x4 v[NI][8];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int it = tid + 256 * i;
+      const int half = it / (IH * NC4), r = it - half * (IH * NC4);
+      const int ry = r / NC4, c4 = r - ry * NC4;
+      const int gy = iy0 + ry, gx = gx0 + 4 * c4;
+      const bool ok = it < NITEM && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;   // (whole chunks are inside or outside)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const unsigned off = ok ? ((unsigned)(8 * half + j) * (unsigned)HW + (unsigned)(gy * a.W + gx)) * 4u : OOBC;
+        v[i][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, off, 0, 0));
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int it = tid + 256 * i;
+      if (it < NITEM) {
+        const int half = it / (IH * NC4), r = it - half * (IH * NC4);
+        const int ry = r / NC4, c4 = r - ry * NC4;
+        unsigned char* dst = xs + half * HALF + (ry * IW + 4 * c4) * 16;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          unsigned hi[4], lo[4];
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) csplit2(v[i][2 * jj][q], v[i][2 * jj + 1][q], hi[jj], lo[jj]);
+          *reinterpret_cast<cu32x4*>(dst + q * 16) = cu32x4{hi[0], hi[1], hi[2], hi[3]};
+          *reinterpret_cast<cu32x4*>(dst + 2 * HALF + q * 16) = cu32x4{lo[0], lo[1], lo[2], lo[3]};
+        }
+      }
+    }
+  } else {
+#pragma unroll 1
+    for (int it = tid; it < NITEM; it += 256) {
+      const int half = it / (IH * NC4), r = it - half * (IH * NC4);
+      const int ry = r / NC4, c4 = r - ry * NC4;
+      const int gy = iy0 + ry, gx = gx0 + 4 * c4;
+      f32x4 v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const bool ok = gy >= 0 && gy < a.H && gx + q >= 0 && gx + q < a.W;
+          const unsigned off = ok ? ((unsigned)(8 * half + j) * (unsigned)HW + (unsigned)(gy * a.W + gx + q)) * 4u : OOBC;
+          v[j][q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_x, off, 0, 0));
+        }
+      unsigned char* dst = xs + half * HALF + (ry * IW + 4 * c4) * 16;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        unsigned hi[4], lo[4];
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) csplit2(v[2 * jj][q], v[2 * jj + 1][q], hi[jj], lo[jj]);
+        *reinterpret_cast<cu32x4*>(dst + q * 16) = cu32x4{hi[0], hi[1], hi[2], hi[3]};
+        *reinterpret_cast<cu32x4*>(dst + 2 * HALF + q * 16) = cu32x4{lo[0], lo[1], lo[2], lo[3]};
+      }
+    }
+  }
+  __syncthreads();
+
+  constexpr int RPW = TH / 4 > 0 ? TH / 4 : 1;                       // rows per wave (2 or 1)
+  float bias_r[MT][4];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) bias_r[m][q] = a.bias ? a.bias[16 * m + 4 * g + q] : 0.f;
+  float* ob = a.out + (long long)b * COUT * a.Ho * a.Wo;
+#pragma unroll 1
+  for (int rr = 0; rr < RPW; ++rr) {
+    const int ty = wid * RPW + rr;
+#pragma unroll 1
+    for (int tx = 0; tx < TW / 16; ++tx) {
+      f32x4 acc[MT];
+#pragma unroll
+      for (int m = 0; m < MT; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const unsigned char* base = xs + ((ty * STRIDE) * IW + (tx * 16 + lpx) * STRIDE + 3) * 16;
+#pragma unroll
+      for (int s_ = 0; s_ < KS; ++s_) {
+        const cbf16x8 bh = *reinterpret_cast<const cbf16x8*>(base + toff[s_]);
+        const cbf16x8 bl = *reinterpret_cast<const cbf16x8*>(base + toff[s_] + 2 * HALF);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+          acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[m][s_], bh, acc[m], 0, 0, 0);
+          acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[m][s_], bl, acc[m], 0, 0, 0);
+          acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[m][s_], bh, acc[m], 0, 0, 0);
+        }
+      }
+      const int oy = oy0 + ty, ox = ox0 + tx * 16 + lpx;
+      if (oy < a.Ho && ox < a.Wo) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            float v = acc[m][q] + bias_r[m][q];
+            if (a.relu) v = fmaxf(v, 0.f);
+            ob[((long long)(16 * m + 4 * g + q) * a.Ho + oy) * a.Wo + ox] = v;
+          }
+      }
+    }
+  }
+}
+
 // ---------------------------------------------------------------- 7x7, 3 -> 16 (the stem) ---
 __global__ __launch_bounds__(256) void conv7x7_c3_kernel(ConvArgs a) {
   constexpr int CIN = 3, TAPS7 = 49, TPAD = 52, KS1 = TPAD / 4, KS = CIN * KS1;   // 13 k-steps per channel
@@ -260,6 +435,14 @@ extern "C" int cp_conv_direct_supported(int32_t Cin, int32_t Cout, int32_t k, in
 extern "C" int cp_conv_direct_forward(const float* x, const float* w, const float* bias, float* out, int32_t B,
                                       int32_t Cin, int32_t H, int32_t W, int32_t Cout, int32_t k, int32_t stride,
                                       int32_t pad, int32_t relu, void* stream) {
+  return cp_conv_direct_forward_ex(x, w, bias, out, B, Cin, H, W, Cout, k, stride, pad, relu, 0, stream);
+}
+
+// split_bf16 != 0: the stride-1 3x3 / 16-input-channel layers (level0) contract in split-bf16 x3 on the bf16 matrix cores
+// (the 7x7 stem has its own split-bf16 kernel, cp_conv7x7_c3_forward); 0: exact fp32 fma chains.
+extern "C" int cp_conv_direct_forward_ex(const float* x, const float* w, const float* bias, float* out, int32_t B,
+                                         int32_t Cin, int32_t H, int32_t W, int32_t Cout, int32_t k, int32_t stride,
+                                         int32_t pad, int32_t relu, int32_t split_bf16, void* stream) {
   CP_CHECK_ARG(x && w && out && B > 0 && H > 0 && W > 0);
   if (!cp_conv_direct_supported(Cin, Cout, k, stride, pad)) return CP_EUNSUPPORTED;
   if ((unsigned long long)Cin * H * W * 4ull >= 0x70000000ull || B > 65535) return CP_EUNSUPPORTED;
@@ -272,9 +455,17 @@ extern "C" int cp_conv_direct_forward(const float* x, const float* w, const floa
     hipLaunchKernelGGL(conv7x7_c3_kernel, dim3((a.Wo + 63) / 64, (a.Ho + 7) / 8, B), dim3(256), 0, st, a);
   } else if (stride == 1) {
     const dim3 grid((a.Wo + 63) / 64, (a.Ho + 7) / 8, B);
-    if (Cout == 16) hipLaunchKernelGGL((conv3x3_c16_kernel<16, 1>), grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((conv3x3_c16_kernel<32, 1>), grid, dim3(256), 0, st, a);
+    if (split_bf16) {
+      if (Cout == 16) hipLaunchKernelGGL((conv3x3_c16_bf16_kernel<16, 1>), grid, dim3(256), 0, st, a);
+      else hipLaunchKernelGGL((conv3x3_c16_bf16_kernel<32, 1>), grid, dim3(256), 0, st, a);
+    } else {
+      if (Cout == 16) hipLaunchKernelGGL((conv3x3_c16_kernel<16, 1>), grid, dim3(256), 0, st, a);
+      else hipLaunchKernelGGL((conv3x3_c16_kernel<32, 1>), grid, dim3(256), 0, st, a);
+    }
   } else {
+    // (stride 2 stays on the exact kernel under either arithmetic: the split-bf16 form -- built, parity-green -- ran
+    // level1 in 93 us against 70: its B fragments sit two cells apart, two-way bank conflicts on every read, and the
+    // staging splits twice the cells per output; tools/probe_conv_direct_bf16.py history in DESIGN 4.10)
     const dim3 grid((a.Wo + 63) / 64, (a.Ho + 3) / 4, B);
     if (Cout == 16) hipLaunchKernelGGL((conv3x3_c16_kernel<16, 2>), grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL((conv3x3_c16_kernel<32, 2>), grid, dim3(256), 0, st, a);

@@ -69,12 +69,13 @@ def _conv_direct(x, conv, wb, relu):
     Ho = (H + 2 * conv.padding[0] - kh) // conv.stride[0] + 1
     Wo = (W + 2 * conv.padding[0] - kh) // conv.stride[0] + 1
     out = torch.empty((B, conv.out_channels, Ho, Wo), dtype=torch.float32, device=x.device)
-    rc = L.cp_conv_direct_forward(_C.ptr(x), _C.ptr(wb[0]), _C.ptr(wb[1]), _C.ptr(out), B, conv.in_channels, H, W,
-                                  conv.out_channels, kh, conv.stride[0], conv.padding[0], 1 if relu else 0,
-                                  _C.stream())
+    # (round 4: under the split-bf16 arithmetic level0 / level1 contract on the bf16 matrix cores like every other layer)
+    rc = L.cp_conv_direct_forward_ex(_C.ptr(x), _C.ptr(wb[0]), _C.ptr(wb[1]), _C.ptr(out), B, conv.in_channels, H, W,
+                                     conv.out_channels, kh, conv.stride[0], conv.padding[0], 1 if relu else 0,
+                                     1 if conv3x3.mfma_enabled() else 0, _C.stream())
     if rc == -2:                                    # CP_EUNSUPPORTED (tensor too large for 32-bit offsets)
         return None
-    _C.check(rc, "cp_conv_direct_forward")
+    _C.check(rc, "cp_conv_direct_forward_ex")
     return out
 
 
@@ -90,8 +91,9 @@ class _DirectConvFn(torch.autograd.Function):
         cout, _, k, _ = weight.shape
         Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
         out = torch.empty((B, cout, Ho, Wo), dtype=torch.float32, device=x.device)
-        _C.check(_C.lib().cp_conv_direct_forward(_C.ptr(x), _C.ptr(weight), None, _C.ptr(out), B, cin, H, W, cout, k,
-                                                 stride, pad, 0, _C.stream()), "cp_conv_direct_forward")
+        _C.check(_C.lib().cp_conv_direct_forward_ex(_C.ptr(x), _C.ptr(weight), None, _C.ptr(out), B, cin, H, W, cout, k,
+                                                    stride, pad, 0, 1 if conv3x3.mfma_enabled() else 0, _C.stream()),
+                 "cp_conv_direct_forward_ex")
         return out
 
     @staticmethod

@@ -215,6 +215,12 @@ int cp_conv_direct_supported(int32_t Cin, int32_t Cout, int32_t k, int32_t strid
 int cp_conv_direct_forward(const float* x, const float* w, const float* bias, float* out, int32_t B, int32_t Cin,
                            int32_t H, int32_t W, int32_t Cout, int32_t k, int32_t stride, int32_t pad,
                            int32_t relu, void* stream);
+/* ABI v3: the same call with the arithmetic as an argument -- split_bf16 != 0 runs the stride-1 3x3 / 16-input-channel
+ * layers (level0 of the DLA base) as split-bf16 x3 on the bf16 matrix cores (fp32 in and out, ~2^-16 per product; the
+ * stride-2 layers keep the exact kernel, which measured faster); 0 = cp_conv_direct_forward (exact fp32 fma chains). */
+int cp_conv_direct_forward_ex(const float* x, const float* w, const float* bias, float* out, int32_t B, int32_t Cin,
+                           int32_t H, int32_t W, int32_t Cout, int32_t k, int32_t stride, int32_t pad,
+                           int32_t relu, int32_t split_bf16, void* stream);
 
 /* 3x3 / stride 1 / pad 1 convolution of float32 NCHW maps on the bf16 matrix cores (split-bf16 x3: float32 in and
  * out, ~2^-16 relative error per product): the dense convolutions of BasicBlock (src/lib/models/networks/

@@ -1177,6 +1177,21 @@ def test_direct_conv_vs_torch_conv2d(cin, cout, k, stride, shape):
         if relu:
             ref = torch.relu(ref)
         np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), rtol=1e-4, atol=1e-5 * ref.abs().max().item())
+        if k == 3:
+            # round 4: the same call under the split-bf16 arithmetic (cp_conv_direct_forward_ex, bf16 matrix cores) against
+            # float64, 2e-5 of the max-norm like every split-bf16 convolution (tests/test_conv_mfma.py); rerun bit-identical
+            ref64 = torch.nn.functional.conv2d(x.cpu().double(), w.cpu().double(), b.cpu().double(), stride=stride, padding=pad)
+            if relu:
+                ref64 = torch.relu(ref64)
+            outs = []
+            for _ in range(2):
+                o2 = torch.full((B, cout, Ho, Wo), float("nan"), device=DEV)
+                _C.check(L.cp_conv_direct_forward_ex(_C.ptr(x), _C.ptr(w), _C.ptr(b), _C.ptr(o2), B, cin, H, W, cout, k,
+                                                     stride, pad, relu, 1, _C.stream()), "cp_conv_direct_forward_ex")
+                outs.append(o2)
+            assert torch.equal(outs[0], outs[1]) and torch.isfinite(outs[0]).all()
+            err = (outs[0].cpu().double() - ref64).abs().max().item() / ref64.abs().max().item()
+            assert err <= 2e-5, err
     assert L.cp_conv_direct_supported(8, 16, 3, 1, 1) == 0
 
 
@@ -1196,6 +1211,11 @@ def test_direct_conv_full_resolution_stem():
                                           pad, 1, _C.stream()), "cp_conv_direct_forward")
         ref = torch.relu(torch.nn.functional.conv2d(x, w, b, stride=stride, padding=pad))
         assert (out - ref).abs().max().item() <= 1e-4 * ref.abs().max().item()
+        if k == 3:                                   # the split-bf16 form at the bench shape (what inference runs)
+            o2 = torch.empty_like(out)
+            _C.check(L.cp_conv_direct_forward_ex(_C.ptr(x), _C.ptr(w), _C.ptr(b), _C.ptr(o2), 1, cin, H, W, cout, k, stride,
+                                                 pad, 1, 1, _C.stream()), "cp_conv_direct_forward_ex")
+            assert (o2 - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()
         x, cin = out, cout
 
 
