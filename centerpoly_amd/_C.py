@@ -96,6 +96,9 @@ _SIGNATURES = {
     "cp_conv_mfma_prepare_batch": (c_int32, [_P, c_int32, c_int32, _P]),
     "cp_conv_mfma_forward": (c_int32, [_P, _P, c_int32, _P, _P, _P, _P] + [c_int32] * 6 + [_P]),
     "cp_conv_mfma_forward_strided": (c_int32, [_P, _P, c_int32, _P, _P, _P, _P] + [c_int32] * 7 + [_P]),
+    "cp_conv_mfma_forward_split": (c_int32, [_P, c_int32, _P, _P, _P, _P] + [c_int32] * 9 + [_P]),
+    "cp_activation_split": (c_int32, [_P, _P] + [c_int32] * 4 + [_P]),
+    "cp_activation_unsplit": (c_int32, [_P, _P] + [c_int32] * 4 + [_P]),
     "cp_conv_mfma_input_grad_relu_workspace_bytes": (c_size_t, [c_int32] * 4),
     "cp_conv_mfma_input_grad_relu": (c_int32, [_P] * 5 + [c_int32] * 6 + [_P, c_size_t, _P]),
     "cp_conv3x3_s2_input_grad": (c_int32, [_P, _P, _P, _P] + [c_int32] * 5 + [_P]),

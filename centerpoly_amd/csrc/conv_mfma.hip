@@ -29,6 +29,9 @@
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 #ifndef CP_CVABL
 #define CP_CVABL 0                  // timing-only ablation bits (tools/probe_conv_ablate.py; results wrong by construction):
@@ -121,6 +124,13 @@ struct CvArgs {
   const float* mask;           // same shape as out, or null: out = mask > 0 ? value : 0 (gradient through a ReLU whose output was `mask`)
   float* colsum;               // null, or [B * tiles * 8][Cout] scratch: row (b, tile, wave, half) = sums of out per channel over RW x 16 pixels
   int Hf, Wf;                  // IG2: the gradient map (element (y, x) of class (py, px) goes to (2 y + py, 2 x + px)); else Ho, Wo
+  // SPLIT activations (round 4): the tensor as two planes [hi | lo] of [B][C / 8][H][W][8 x bf16] -- what the staging
+  // below builds from float32 anyway, written once by the PRODUCER's epilogue (out_split) and staged by the consumer
+  // (template PRE, xpre) with two 16-byte loads per unit and no conversion arithmetic.  Same bytes as float32.
+  const bf16x8* xpre = nullptr;   // PRE: the input's hi plane; lo plane at + pre_plane units
+  long long pre_plane = 0;
+  int out_split = 0;              // the output leaves as split planes (out = hi plane, lo at + out_plane units); Cout % 8 == 0
+  long long out_plane = 0;
 };
 
 // KS > 1 (deep, small layers whose grid cannot fill the chip -- one wave per SIMD exposes every load latency): the
@@ -136,9 +146,14 @@ struct CvArgs {
 // the four parity classes of the gradient's rows / columns keep their own accumulators (4 x MT x NT tiles), every one
 // of the nine weight taps (ky, kx) feeds the class ((ky != 1), (kx != 1)) from the staged row / column offset
 // (ky == 0 ? 2 : 1, kx == 0 ? 2 : 1): grad_out is staged once and the matrix cores do exactly the convolution's flops.
-template <int MT, int RW, int TAPS, int KS = 1, int ST = 1, bool IG2 = false>
+template <int MT, int RW, int TAPS, int KS = 1, int ST = 1, bool IG2 = false, bool PRE = false, bool OSPLIT = false>
 __global__ __launch_bounds__(256 * KS, KS > 1 ? 4 : 2) void conv_mfma_kernel(CvArgs a) {
   static_assert(!IG2 || (TAPS == 9 && KS == 1 && ST == 1), "IG2: 3x3, stride-1 staging, no split-K");
+  static_assert(!PRE || (TAPS == 9 && ST == 1 && !IG2), "PRE: 3x3 / stride 1 forward");
+  static_assert(!OSPLIT || !IG2, "split planes out: forward forms");
+  // orientation of the accumulator tiles: channels x pixels (lane = 4 channels of a pixel: the split-plane and the
+  // stride-2 gradient epilogues) or pixels x channels (lane = 4 consecutive pixels of a channel: float32 NCHW out)
+  constexpr bool TRD = !IG2 && !OSPLIT;
   constexpr int NCLS = IG2 ? 4 : 1;
 #ifdef CP_CVSTAMP
   unsigned long long stamp[16];
@@ -178,7 +193,9 @@ __global__ __launch_bounds__(256 * KS, KS > 1 ? 4 : 2) void conv_mfma_kernel(CvA
     const int col = u % LW, r = (u / LW) % LH, cg = u / (LW * LH);
     const int gy = SUB * (S * y0 - HALO + r), gx = SUB * (S * x0 - HALO + col);
     const bool ok = u < UNITS && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-    soff[i] = ok ? ((unsigned)(cg * 8) * (unsigned)HW + (unsigned)(gy * a.W + gx)) * 4u : OOB;
+    soff[i] = !ok ? OOB
+              : PRE ? ((unsigned)cg * (unsigned)HW + (unsigned)(gy * a.W + gx)) * 16u
+                    : ((unsigned)(cg * 8) * (unsigned)HW + (unsigned)(gy * a.W + gx)) * 4u;
   }
   const unsigned cstep = (unsigned)HW * 4u;
 
@@ -245,6 +262,34 @@ __global__ __launch_bounds__(256 * KS, KS > 1 ? 4 : 2) void conv_mfma_kernel(CvA
       }
     }
   };
+  // PRE: the unit is already [8 x bf16] in both planes -- two 16-byte loads, two 16-byte LDS stores
+  const long long pre_img = PRE ? (long long)b * (a.Cin >> 3) * HW : 0;
+  const int pre_bytes = PRE ? (int)((unsigned)(a.Cin >> 3) * (unsigned)HW * 16u) : 0;
+  const __amdgpu_buffer_rsrc_t rs_ph = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<bf16x8*>(PRE ? a.xpre + pre_img : a.wp), 0, pre_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_pl = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<bf16x8*>(PRE ? a.xpre + a.pre_plane + pre_img : a.wp), 0, pre_bytes, 0x00020000);
+  auto load_pre = [&](int chunk, int i0, auto& vh, auto& vl) {
+    const unsigned cb = (unsigned)chunk * 4u * (unsigned)HW * 16u;
+    constexpr int N = sizeof(vh) / sizeof(vh[0]);
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      const unsigned o = (i0 + i >= ITERS || soff[(i0 + i) % ITERS] == OOB) ? OOB : soff[(i0 + i) % ITERS] + cb;
+      vh[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_ph, o, 0, 0);
+      vl[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_pl, o, 0, 0);
+    }
+  };
+  auto store_pre = [&](int i0, auto& vh, auto& vl) {
+    constexpr int N = sizeof(vh) / sizeof(vh[0]);
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      const int u = tid + (i0 + i) * 256;
+      if (i0 + i < ITERS && u < UNITS) {
+        Xs[u] = __builtin_bit_cast(bf16x8, vh[i]);
+        Xs[PLANE + u] = __builtin_bit_cast(bf16x8, vl[i]);
+      }
+    }
+  };
   auto bread = [&](int tap, bf16x8 (&bh)[NT], bf16x8 (&bl)[NT]) {
     const int dy = IG2 ? (tap / 3 == 0 ? 2 : 1) : tap / 3, dx = IG2 ? (tap % 3 == 0 ? 2 : 1) : tap % 3;
 #pragma unroll
@@ -264,9 +309,15 @@ __global__ __launch_bounds__(256 * KS, KS > 1 ? 4 : 2) void conv_mfma_kernel(CvA
     if (active && !(CP_CVABL & 16)) {
 #pragma unroll
       for (int i0 = 0; i0 < ITERS; i0 += SB) {                // batches of SB units: 8 SB loads in flight per thread
-        float v[SB][8];
-        load(chunk, i0, v);
-        store(i0, v);
+        if constexpr (PRE) {
+          u32x4 vh[SB], vl[SB];
+          load_pre(chunk, i0, vh, vl);
+          store_pre(i0, vh, vl);
+        } else {
+          float v[SB][8];
+          load(chunk, i0, v);
+          store(i0, v);
+        }
       }
     }
 #ifdef CP_CVSTAMP
@@ -305,9 +356,15 @@ __global__ __launch_bounds__(256 * KS, KS > 1 ? 4 : 2) void conv_mfma_kernel(CvA
               d[0] += (float)bh[n][0] * (float)af[m][0][0] + (float)bl[n][1] * (float)af[m][1][1];
               continue;
             }
-            d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[m][0], bh[n], d, 0, 0, 0);
-            d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[m][0], bl[n], d, 0, 0, 0);
-            d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[m][1], bh[n], d, 0, 0, 0);
+            if constexpr (TRD) {
+              d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[n], af[m][0], d, 0, 0, 0);
+              d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl[n], af[m][0], d, 0, 0, 0);
+              d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[n], af[m][1], d, 0, 0, 0);
+            } else {
+              d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[m][0], bh[n], d, 0, 0, 0);
+              d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[m][0], bl[n], d, 0, 0, 0);
+              d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[m][1], bh[n], d, 0, 0, 0);
+            }
           }
       }
 #pragma unroll
@@ -380,14 +437,48 @@ __global__ __launch_bounds__(256 * KS, KS > 1 ? 4 : 2) void conv_mfma_kernel(CvA
     }
     return;
   }
-  // The accumulators hold (co = 4 g + r, px = c) and, in the tile to the right, (co, px = 16 + c): 64-byte runs per
-  // channel.  v_permlane16_swap trades the odd 16-lane rows of the left tile with the even rows of the right one, so
-  // that a row PAIR (g & ~1, g | 1) carries 32 consecutive pixels of one channel -- every store / residual / mask
-  // access of the epilogue is a whole 128-byte line (the 1x1 forms and the masked input gradient are bound by them).
-  // Branch-free: invalid elements get an offset past the descriptor's range (loads return 0, stores are dropped), so
-  // the residual / mask loads of a 16-channel fragment row are all in flight together (with a branch per element every
-  // load waited out its own latency: the masked input gradient of the heads ran 4x over its traffic).
-  const int x = x0 + c + 16 * (g & 1);
+  if constexpr (OSPLIT) {
+    // split planes out: the lane's four consecutive channels (4 g .. 4 g + 3) of its pixel are half a unit -- one
+    // 8-byte store per plane; the lanes of a row pair (g, g | 1) x 16 pixels fill 256 contiguous bytes per store
+    const long long img = (long long)b * (a.Cout >> 3) * HWf;
+    const int obytes = (int)((unsigned)(a.Cout >> 3) * (unsigned)HWf * 16u);
+    bf16x8* oh = reinterpret_cast<bf16x8*>(a.out) + img;
+    const __amdgpu_buffer_rsrc_t rs_h = __builtin_amdgcn_make_buffer_rsrc(oh, 0, obytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_l = __builtin_amdgcn_make_buffer_rsrc(oh + a.out_plane, 0, obytes, 0x00020000);
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      const int co0 = (cot * MT + m) * 16 + 4 * g;
+      float bv[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) bv[r] = (a.bias && co0 + r < a.Cout) ? a.bias[co0 + r] : 0.f;
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        const int y = y0 + wid * RW + (n >> 1), xx = x0 + (n & 1) * 16 + c;
+        const bool ok = co0 < a.Cout && y < a.Ho && xx < a.Wo;
+        bf16x4 h, l;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float v = acc[m][n][r] + bv[r];
+          if (a.relu) v = fmaxf(v, 0.f);
+          const __bf16 hh = (__bf16)v;
+          h[r] = hh;
+          l[r] = (__bf16)(v - (float)hh);
+        }
+        const unsigned off = ok ? ((unsigned)(co0 >> 3) * (unsigned)HWf + (unsigned)(y * a.Wf + xx)) * 16u + (unsigned)(g & 1) * 8u
+                                : 0x80000000u;
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, h), rs_h, off, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, l), rs_l, off, 0, 0);
+      }
+    }
+    return;
+  }
+  // Float32 output.  The matrix instruction runs TRANSPOSED here (pixels on the M side, channels on the N side -- the
+  // two operands have the same register layout, so it is only their order): lane (g, c) holds the four consecutive
+  // pixels 4 g .. 4 g + 3 of channel c, i.e. ONE 16-byte store / residual / mask access per accumulator tile, 16
+  // channels x 64 contiguous bytes per wave instruction (round 4; before: dword accesses on 128-byte lines behind a
+  // v_permlane16_swap, 4x the vector-memory instructions -- the split-plane epilogue above showed what they cost).
+  // Branch-free: invalid elements get an offset past the descriptor's range (loads return 0, stores are dropped).
+  // Maps whose width is not a multiple of 4 (or unaligned tensors) take dword accesses element by element.
   const int cot0 = cot * MT * 16;
   const unsigned span = (unsigned)min(a.Cout - cot0, MT * 16) * (unsigned)HWf * 4u;       // this workgroup's channels
   const long long tbase = (long long)b * a.Cout * HWf + (long long)cot0 * HWf;
@@ -397,55 +488,62 @@ __global__ __launch_bounds__(256 * KS, KS > 1 ? 4 : 2) void conv_mfma_kernel(CvA
   const __amdgpu_buffer_rsrc_t rs_m =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.mask ? a.mask + tbase : a.out), 0, a.mask ? (int)span : 0, 0x00020000);
   constexpr unsigned EOOB = 0x80000000u;
+  const bool vec = (a.Wf & 3) == 0 && ((reinterpret_cast<unsigned long long>(a.out) | reinterpret_cast<unsigned long long>(a.res) |
+                                        reinterpret_cast<unsigned long long>(a.mask)) & 15) == 0;
 #pragma unroll
   for (int m = 0; m < MT; ++m) {
-    unsigned off[4][RW][2];
-    float val[4][RW][2], rv[4][RW][2], mv[4][RW][2];
+    const int cl = m * 16 + c;                                   // channel within the workgroup's tile
+    const bool cok = cot0 + cl < a.Cout;
+    const float bv = (a.bias && cok) ? a.bias[cot0 + cl] : 0.f;
+    unsigned off[NT];
+    f32x4 rv[NT], mv[NT];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int col[2] = {m * 16 + r + 4 * (g & ~1), m * 16 + r + 4 * (g | 1)};      // channel within the workgroup's tile
+    for (int n = 0; n < NT; ++n) {
+      const int y = y0 + wid * RW + (n >> 1), x = x0 + (n & 1) * 16 + 4 * g;
+      off[n] = (cok && y < a.Ho && x < a.Wo) ? ((unsigned)cl * (unsigned)HWf + (unsigned)(y * a.Wf + x)) * 4u : EOOB;
+      if (vec) {
+        if (a.res) rv[n] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_r, off[n], 0, 0));
+        if (a.mask) mv[n] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_m, off[n], 0, 0));
+      } else {
 #pragma unroll
-      for (int rp = 0; rp < RW; ++rp) {
-        // (__builtin_bit_cast of a vector ELEMENT lvalue reads element 0 under hipcc 7.2: copy to scalars first)
-        const float e0 = acc[m][2 * rp][r], e1 = acc[m][2 * rp + 1][r];
-        const auto sw = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, e0), __builtin_bit_cast(unsigned, e1),
-                                                         false, false);
-        val[r][rp][0] = __builtin_bit_cast(float, (unsigned)sw[0]);
-        val[r][rp][1] = __builtin_bit_cast(float, (unsigned)sw[1]);
-        const int y = y0 + wid * RW + rp;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const bool ok = cot0 + col[j] < a.Cout && y < a.Ho && x < a.Wo;
-          off[r][rp][j] = ok ? ((unsigned)col[j] * (unsigned)HWf + (unsigned)(y * a.Wf + x)) * 4u : EOOB;
-          if (a.res) rv[r][rp][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_r, off[r][rp][j], 0, 0));
-          if (a.mask) mv[r][rp][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_m, off[r][rp][j], 0, 0));
+        for (int r = 0; r < 4; ++r) {
+          const unsigned o = (off[n] != EOOB && x + r < a.Wo) ? off[n] + 4u * r : EOOB;
+          if (a.res) rv[n][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_r, o, 0, 0));
+          if (a.mask) mv[n][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_m, o, 0, 0));
         }
       }
     }
+    float csum[2] = {0.f, 0.f};
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int co[2] = {cot0 + m * 16 + r + 4 * (g & ~1), cot0 + m * 16 + r + 4 * (g | 1)};
-      float csum[2] = {0.f, 0.f};
+    for (int n = 0; n < NT; ++n) {
+      const int x = x0 + (n & 1) * 16 + 4 * g;
+      f32x4 v;
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const float bv = (a.bias && co[j] < a.Cout) ? a.bias[co[j]] : 0.f;
-#pragma unroll
-        for (int rp = 0; rp < RW; ++rp) {
-          float v = val[r][rp][j] + bv;
-          if (a.res) v += rv[r][rp][j];
-          if (a.relu) v = fmaxf(v, 0.f);
-          if (a.mask && !(mv[r][rp][j] > 0.f)) v = 0.f;
-          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs_o, off[r][rp][j], 0, 0);
-          csum[j] += off[r][rp][j] == EOOB ? 0.f : v;
-        }
+      for (int r = 0; r < 4; ++r) {
+        float t = acc[m][n][r] + bv;
+        if (a.res) t += rv[n][r];
+        if (a.relu) t = fmaxf(t, 0.f);
+        if (a.mask && !(mv[n][r] > 0.f)) t = 0.f;
+        v[r] = t;
+        csum[n & 1] += (off[n] != EOOB && x + r < a.Wo) ? t : 0.f;
       }
-      if (a.colsum) {                                          // (wave-uniform) this 16-lane row's RW x 16 pixels of co[0], co[1]
-        const long long row = ((((long long)b * (gridDim.x / a.ncot) + tile) * 4 + wid) * 2 + (g & 1)) * a.Cout;
+      if (vec) {
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs_o, off[n], 0, 0);
+      } else {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const float t = row16_sum(csum[j]);
-          if (c == 0 && co[j] < a.Cout) a.colsum[row + co[j]] = t;
-        }
+        for (int r = 0; r < 4; ++r)
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, (float)v[r]), rs_o,
+                                                (off[n] != EOOB && x + r < a.Wo) ? off[n] + 4u * r : EOOB, 0, 0);
+      }
+    }
+    if (a.colsum) {                                              // (wave-uniform) per wave and 16-pixel half: this channel's sum
+      const long long row0 = (((long long)b * (gridDim.x / a.ncot) + tile) * 4 + wid) * 2;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        float t = csum[h];
+        t += __shfl_xor(t, 16);
+        t += __shfl_xor(t, 32);
+        if (g == 0 && cok) a.colsum[(row0 + h) * a.Cout + cot0 + cl] = t;
       }
     }
   }
@@ -546,15 +644,28 @@ static int conv_dispatch(CvArgs& a, int B, int Cout, int taps, int stride, hipSt
     else if (wgs(2, 4) < 384 && a.nchunk >= 8) launch(conv_mfma_kernel<2, 1, 1, 4, 2>, 2, 4, 4);
     else launch(conv_mfma_kernel<2, 1, 1, 1, 2>, 2, 4, 1);
   } else if (stride == 2) {                          // 4-row tiles only (the staged tile is 9 x 65 pixels)
-    if (Cout > 32 && wgs(4, 4) >= 448) launch(conv_mfma_kernel<4, 1, 9, 1, 2>, 4, 4, 1);
-    else launch(conv_mfma_kernel<2, 1, 9, 1, 2>, 2, 4, 1);
-  } else if (taps == 9) {
-    if (Cout > 32 && wgs(4, 8) >= 448) launch(conv_mfma_kernel<4, 2, 9>, 4, 8, 1);
-    else if (Cout <= 32 && wgs(2, 16) >= 448) launch(conv_mfma_kernel<2, 4, 9>, 2, 16, 1);
-    else if (wgs(2, 8) >= 320) launch(conv_mfma_kernel<2, 2, 9>, 2, 8, 1);
-    else if (wgs(2, 4) < 384 && a.nchunk >= 8) launch(conv_mfma_kernel<2, 1, 9, 4>, 2, 4, 4);   // in-workgroup K split
-    else if (wgs(2, 4) < 768 && a.nchunk >= 4) launch(conv_mfma_kernel<2, 1, 9, 2>, 2, 4, 2);
-    else launch(conv_mfma_kernel<2, 1, 9>, 2, 4, 1);
+    const bool big = Cout > 32 && wgs(4, 4) >= 448;
+    if (a.out_split) {
+      if (big) launch(conv_mfma_kernel<4, 1, 9, 1, 2, false, false, true>, 4, 4, 1);
+      else launch(conv_mfma_kernel<2, 1, 9, 1, 2, false, false, true>, 2, 4, 1);
+    } else {
+      if (big) launch(conv_mfma_kernel<4, 1, 9, 1, 2>, 4, 4, 1);
+      else launch(conv_mfma_kernel<2, 1, 9, 1, 2>, 2, 4, 1);
+    }
+  } else if (taps == 9) {                            // split-plane input / output: the same tile choice, other staging / epilogue
+    auto pick = [&](auto pre, auto os) {
+      constexpr bool PRE = decltype(pre)::value, OS = decltype(os)::value;
+      if (Cout > 32 && wgs(4, 8) >= 448) launch(conv_mfma_kernel<4, 2, 9, 1, 1, false, PRE, OS>, 4, 8, 1);
+      else if (Cout <= 32 && wgs(2, 16) >= 448) launch(conv_mfma_kernel<2, 4, 9, 1, 1, false, PRE, OS>, 2, 16, 1);
+      else if (wgs(2, 8) >= 320) launch(conv_mfma_kernel<2, 2, 9, 1, 1, false, PRE, OS>, 2, 8, 1);
+      else if (wgs(2, 4) < 384 && a.nchunk >= 8) launch(conv_mfma_kernel<2, 1, 9, 4, 1, false, PRE, OS>, 2, 4, 4);   // in-workgroup K split
+      else if (wgs(2, 4) < 768 && a.nchunk >= 4) launch(conv_mfma_kernel<2, 1, 9, 2, 1, false, PRE, OS>, 2, 4, 2);
+      else launch(conv_mfma_kernel<2, 1, 9, 1, 1, false, PRE, OS>, 2, 4, 1);
+    };
+    if (a.xpre && a.out_split) pick(std::true_type{}, std::true_type{});
+    else if (a.xpre) pick(std::true_type{}, std::false_type{});
+    else if (a.out_split) pick(std::false_type{}, std::true_type{});
+    else pick(std::false_type{}, std::false_type{});
   } else {                                          // 1x1: bandwidth-bound, the grid only has to fill the chip
     if (Cout > 32 && wgs(4, 8) >= 448) launch(conv_mfma_kernel<4, 2, 1>, 4, 8, 1);
     else if (wgs(2, 8) >= 320) launch(conv_mfma_kernel<2, 2, 1>, 2, 8, 1);
@@ -568,7 +679,7 @@ static int conv_dispatch(CvArgs& a, int B, int Cout, int taps, int stride, hipSt
 static int conv_forward_impl(const float* const* xs, const int32_t* cs, int32_t nsrc, const void* wperm, const float* bias,
                              const float* residual, const float* mask, float* colsum, float* out, int32_t B, int32_t H,
                              int32_t W, int32_t Cout, int32_t taps, int32_t stride, int32_t relu, void* stream,
-                             int* tiles_out = nullptr) {
+                             int* tiles_out = nullptr, int x_split = 0, int out_split = 0) {
   hipStream_t st = (hipStream_t)stream;
   CP_CHECK_ARG(xs && cs && wperm && out && B >= 1 && nsrc >= 1 && nsrc <= MAXSRC && (taps == 1 || taps == 9));
   if (stride != 1 && stride != 2) return CP_EUNSUPPORTED;
@@ -600,7 +711,78 @@ static int conv_forward_impl(const float* const* xs, const int32_t* cs, int32_t 
   a.Hf = a.Ho; a.Wf = a.Wo;
   a.mask = mask; a.colsum = colsum;
   if ((long long)a.Ho * a.Wo * 64 * 4 >= 0x7FFFFFF0ll) return CP_EUNSUPPORTED;     // (32-bit offsets within a channel tile)
+  if (x_split) {                                     // xs[0] = the hi plane of a split tensor
+    if (nsrc != 1 || taps != 9 || stride != 1 || Cin % KC != 0) return CP_EUNSUPPORTED;
+    a.xpre = reinterpret_cast<const bf16x8*>(xs[0]);
+    a.pre_plane = (long long)B * (Cin / 8) * H * W;
+  }
+  if (out_split) {
+    if (Cout % 8 != 0 || residual || mask || colsum || taps != 9) return CP_EUNSUPPORTED;
+    a.out_split = 1;
+    a.out_plane = (long long)B * (Cout / 8) * a.Ho * a.Wo;
+  }
   return conv_dispatch(a, B, Cout, taps, stride, st, tiles_out);
+}
+
+// float32 [B][C][H][W] <-> split planes [hi | lo][B][C / 8][H][W][8 x bf16] (hi = bf16(v), lo = bf16(v - hi): the
+// staging's own split, so a convolution of the split tensor equals the convolution of the float32 one bit for bit)
+__global__ __launch_bounds__(256) void activation_split_kernel(const float* __restrict__ x, bf16x8* __restrict__ out,
+                                                               long long HW, long long plane) {
+  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= plane) return;
+  const long long bc = e / HW, p = e % HW;
+  bf16x8 h, l;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float v = x[(bc * 8 + j) * HW + p];
+    const __bf16 hh = (__bf16)v;
+    h[j] = hh;
+    l[j] = (__bf16)(v - (float)hh);
+  }
+  out[e] = h;
+  out[plane + e] = l;
+}
+
+__global__ __launch_bounds__(256) void activation_unsplit_kernel(const bf16x8* __restrict__ in, float* __restrict__ x,
+                                                                 long long HW, long long plane) {
+  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= plane) return;
+  const long long bc = e / HW, p = e % HW;
+  const bf16x8 h = in[e], l = in[plane + e];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) x[(bc * 8 + j) * HW + p] = (float)h[j] + (float)l[j];
+}
+
+int cp_activation_split(const float* x, void* out, int32_t B, int32_t C, int32_t H, int32_t W, void* stream) {
+  CP_CHECK_ARG(x && out && B >= 1 && C >= 8 && H >= 1 && W >= 1);
+  if (C % 8 != 0) return CP_EUNSUPPORTED;
+  const long long HW = (long long)H * W, plane = (long long)B * (C / 8) * HW;
+  if (plane >= 0x7FFFFFFFll * 256) return CP_EUNSUPPORTED;
+  hipLaunchKernelGGL(activation_split_kernel, dim3((unsigned)((plane + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x,
+                     (bf16x8*)out, HW, plane);
+  return cp_launch_status();
+}
+
+int cp_activation_unsplit(const void* in, float* x, int32_t B, int32_t C, int32_t H, int32_t W, void* stream) {
+  CP_CHECK_ARG(x && in && B >= 1 && C >= 8 && H >= 1 && W >= 1);
+  if (C % 8 != 0) return CP_EUNSUPPORTED;
+  const long long HW = (long long)H * W, plane = (long long)B * (C / 8) * HW;
+  if (plane >= 0x7FFFFFFFll * 256) return CP_EUNSUPPORTED;
+  hipLaunchKernelGGL(activation_unsplit_kernel, dim3((unsigned)((plane + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16x8*)in, x, HW, plane);
+  return cp_launch_status();
+}
+
+// cp_conv_mfma_forward_strided for ONE source whose input and / or output are split planes (x_split: 3x3 / stride 1
+// and Cin % 32 == 0 only; out_split: Cout % 8 == 0, no residual).  The planes hold exactly the halves the float32
+// form's staging computes, so the results are bit-identical to the float32 route.
+int cp_conv_mfma_forward_split(const void* x, int32_t x_split, const void* wperm, const float* bias, const float* residual,
+                               void* out, int32_t out_split, int32_t B, int32_t Cin, int32_t H, int32_t W, int32_t Cout,
+                               int32_t taps, int32_t stride, int32_t relu, void* stream) {
+  const float* xs[1] = {reinterpret_cast<const float*>(x)};
+  const int32_t cs[1] = {Cin};
+  return conv_forward_impl(xs, cs, 1, wperm, bias, residual, nullptr, nullptr, reinterpret_cast<float*>(out), B, H, W, Cout,
+                           taps, stride, relu, stream, nullptr, x_split ? 1 : 0, out_split ? 1 : 0);
 }
 
 int cp_conv_mfma_forward_strided(const float* const* xs, const int32_t* cs, int32_t nsrc, const void* wperm,

@@ -167,13 +167,20 @@ def _launch(x, wp, bias, residual, cout, relu, taps=9, stride=1):
     return out
 
 
-def conv_infer(xs, owner, w, bias=None, residual=None, relu=False, conv=None, key="_mfma_wperm"):
+def conv_infer(xs, owner, w, bias=None, residual=None, relu=False, conv=None, key="_mfma_wperm", x_split=False,
+               out_split=False):
     """Inference: 3x3 / pad 1 or 1x1 (stride 1 or 2) convolution of the channel concatenation of `xs` -- read in place,
     no torch.cat -- with the (folded) weight `w`, + bias + residual + ReLU in the kernel's epilogue.  The permuted
     weights are cached on `owner` (under `key`) for as long as `w` is the same, unmodified tensor.  `conv`, when
-    given, is the module whose geometry must be the kernel's.  Returns None when the shape is not the kernel's."""
+    given, is the module whose geometry must be the kernel's.  Returns None when the shape is not the kernel's.
+    x_split / out_split (one source, 3x3): the input / output is a SPLIT tensor -- the [hi | lo] bf16 planes of
+    cp_conv_mfma_forward_split held in a float32 tensor of the logical shape (same bytes; only such a convolution may
+    read it).  Bit-identical to the float32 route."""
     k = tuple(w.shape[2:])
     if not _ENABLED or k not in ((1, 1), (3, 3)):
+        return None
+    if (x_split or out_split) and (len(xs) != 1 or k != (3, 3) or (out_split and residual is not None)
+                                   or (x_split and xs[0].shape[1] % 32) or (out_split and w.shape[0] % 8)):
         return None
     stride = 1
     if conv is not None:
@@ -208,12 +215,43 @@ def conv_infer(xs, owner, w, bias=None, residual=None, relu=False, conv=None, ke
     chans = (_C.c_int32 * len(xs))(*cs)
     tag = "conv3x3_fwd" if taps == 9 and stride == 1 else ("conv3x3s2_fwd" if taps == 9 else "conv1x1_fwd")
     end = _C.kernel_timer.start((tag, cin, cout, H, W, B)) if _C.kernel_timer is not None else None
-    _C.check(L.cp_conv_mfma_forward_strided(ptrs, chans, len(xs), _C.ptr(cache[2]), _C.ptr(bias), _C.ptr(residual),
-                                            _C.ptr(out), B, H, W, cout, taps, stride, 1 if relu else 0, _C.stream()),
-             "cp_conv_mfma_forward_strided")
+    if x_split or out_split:
+        if x_split and stride != 1:
+            return None
+        _C.check(L.cp_conv_mfma_forward_split(_C.ptr(xs[0]), 1 if x_split else 0, _C.ptr(cache[2]), _C.ptr(bias),
+                                              _C.ptr(residual), _C.ptr(out), 1 if out_split else 0, B, cin, H, W, cout,
+                                              taps, stride, 1 if relu else 0, _C.stream()), "cp_conv_mfma_forward_split")
+    else:
+        _C.check(L.cp_conv_mfma_forward_strided(ptrs, chans, len(xs), _C.ptr(cache[2]), _C.ptr(bias), _C.ptr(residual),
+                                                _C.ptr(out), B, H, W, cout, taps, stride, 1 if relu else 0, _C.stream()),
+                 "cp_conv_mfma_forward_strided")
     if end is not None:
         end.record()
     return out
+
+
+def block_infer(x, conv1, wb1, conv2, wb2, skip):
+    """relu(conv2(relu(conv1(x) + b1)) + b2 + skip) of a residual block at inference (pose_dla_dcn.py BasicBlock :38-66,
+    large_hourglass.py residual :55-81) with the intermediate kept as split planes: conv1's epilogue writes the bf16
+    halves conv2's staging would otherwise form from float32, conv2 stages them with 16-byte loads.  None when the pair
+    is not two launches of the MFMA kernel (the caller then runs the float32 route)."""
+    planes = wb1[0].shape[0]
+    if not (_ENABLED and x.is_cuda and planes % 32 == 0 and tuple(wb1[0].shape[2:]) == (3, 3)
+            and tuple(wb2[0].shape[2:]) == (3, 3) and conv2.stride == (1, 1)):
+        return None
+    B, _, H, W = x.shape
+    s = conv1.stride[0]
+    Ho, Wo = (H - 1) // s + 1, (W - 1) // s + 1
+    if planes < MIN_CIN or not _fills(B, planes, planes, Ho, Wo) \
+            or not _C.lib().cp_conv3x3_mfma_supported(planes, planes, Ho, Wo) or (skip is not None and not skip.is_contiguous()):
+        return None                                  # conv2 would refuse the split tensor
+    y = conv_infer([x], conv1, wb1[0], wb1[1], None, True, conv=conv1, out_split=True)
+    if y is None:
+        return None
+    z = conv_infer([y], conv2, wb2[0], wb2[1], skip, True, conv=conv2, x_split=True)
+    if z is None:
+        raise _C.NativeError("block_infer: the second convolution refused a split tensor its first convolution wrote")
+    return z
 
 
 def conv3x3_infer(x, owner, w, bias=None, residual=None, relu=False, conv=None, key="_mfma_wperm"):

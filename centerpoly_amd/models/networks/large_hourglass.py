@@ -14,6 +14,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ... import _C
+from . import conv3x3
 from .conv3x3 import conv3x3_infer
 from .pose_dla_dcn import _conv_folded, _fold_conv_bn, _use_folded, bn_act, conv_train, flush_batch_counts, heads_fused_infer
 
@@ -70,6 +71,9 @@ class residual(nn.Module):
         if _use_folded(self):
             f1, f2, fs = self._folded
             skip = x if fs is None else _conv_folded(x, self.skip[0], fs, relu=False)
+            z = conv3x3.block_infer(x, self.conv1, f1, self.conv2, f2, skip)
+            if z is not None:                       # the intermediate as split bf16 planes (bit-identical)
+                return z
             y = _conv_folded(x, self.conv1, f1, relu=True)
             return _conv_folded(y, self.conv2, f2, relu=True, residual=skip)
         y = bn_act(self.bn1, conv_train(self.conv1, x), relu=True)

@@ -345,6 +345,9 @@ class BasicBlock(nn.Module):
     def forward(self, x, residual=None):
         skip = x if residual is None else residual
         if _use_folded(self):
+            z = conv3x3.block_infer(x, self.conv1, self._folded[0], self.conv2, self._folded[1], skip)
+            if z is not None:                       # the intermediate as split bf16 planes (bit-identical)
+                return z
             y = _conv_folded(x, self.conv1, self._folded[0], relu=True)
             return _conv_folded(y, self.conv2, self._folded[1], relu=True, residual=skip)
         pair = conv3x3.conv_raw_skip(self.conv1, x) if (residual is None and x.is_cuda and self.training) else None

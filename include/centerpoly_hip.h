@@ -267,6 +267,18 @@ int cp_conv_mfma_forward(const float* const* xs, const int32_t* cs, int32_t nsrc
 int cp_conv_mfma_forward_strided(const float* const* xs, const int32_t* cs, int32_t nsrc, const void* wperm,
                                  const float* bias, const float* residual, float* out, int32_t B, int32_t H, int32_t W,
                                  int32_t Cout, int32_t taps, int32_t stride, int32_t relu, void* stream);
+/* SPLIT activations (round 4; inference, between the two convolutions of a BasicBlock, pose_dla_dcn.py:38-66): a
+ * float32 tensor [B][C][H][W] kept as two planes [hi | lo] of [B][C / 8][H][W][8 x bf16] (hi = bf16(v), lo =
+ * bf16(v - hi): the halves the convolution's staging forms anyway; same bytes as float32; C % 8 == 0).  The producer's
+ * epilogue writes them (out_split), the consumer stages them with two 16-byte loads per unit and no conversion
+ * arithmetic (x_split: 3x3 / stride 1, Cin % 32 == 0).  Results are bit-identical to the float32 route.
+ * cp_conv_mfma_forward_split = cp_conv_mfma_forward_strided for one source; x / out are float32 tensors or split
+ * planes as the flags say (out_split: no residual).  cp_activation_split / _unsplit convert (tests, probes). */
+int cp_conv_mfma_forward_split(const void* x, int32_t x_split, const void* wperm, const float* bias, const float* residual,
+                               void* out, int32_t out_split, int32_t B, int32_t Cin, int32_t H, int32_t W, int32_t Cout,
+                               int32_t taps, int32_t stride, int32_t relu, void* stream);
+int cp_activation_split(const float* x, void* out, int32_t B, int32_t C, int32_t H, int32_t W, void* stream);
+int cp_activation_unsplit(const void* in, float* x, int32_t B, int32_t C, int32_t H, int32_t W, void* stream);
 /* Weight gradient of a 3x3 / stride 2 / pad 1 convolution (the first convolution of DLA levels 2-5,
  * src/lib/models/networks/pose_dla_dcn.py:32-40; cuDNN's backward-filter in the reference), same arithmetic:
  *   gw[co][ci][ky][kx] += sum_{b,i,j} grad_out[b][co][i][j] * x[b][ci][2 i + ky - 1][2 j + kx - 1]
