@@ -57,7 +57,9 @@ __global__ __launch_bounds__(256) void conv3x3_c16_kernel(ConvArgs a) {
   const int iy0 = oy0 * STRIDE - 1;
   const int HW = a.H * a.W;
 
-  // weights -> registers: A[co = 16 m + lpx][k = 4 ks + g], k = tap * 16 + ci
+  // weights -> registers: A[co = 16 m + lpx][k = 4 ks + g], k = tap * 16 + ci (gathers straight from global memory, in
+  // flight together with the tile's loads; staging them through LDS as the bf16 kernel below does was measured here:
+  // level0 125 -> 150 us, level1 71 -> 84 -- two more barriers in front of a kernel that runs two workgroups per CU)
   float wa[MT][KS];
 #pragma unroll
   for (int m = 0; m < MT; ++m)
@@ -122,30 +124,40 @@ __global__ __launch_bounds__(256) void conv3x3_c16_kernel(ConvArgs a) {
 #pragma unroll 1
   for (int rr = 0; rr < RPW; ++rr) {
     const int ty = wid * RPW + rr;
-#pragma unroll 1
-    for (int tx = 0; tx < TW / 16; ++tx) {
-      f32x4 acc[MT];
+    // the row's four 16-pixel tiles together: independent accumulator chains keep the matrix pipe issuing (one tile at
+    // a time was a chain of 36 dependent MFMAs per output-channel fragment)
+    constexpr int NTX = TW / 16;
+    f32x4 acc[MT][NTX];
 #pragma unroll
-      for (int m = 0; m < MT; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
-      const float* base = xs + g * PLANE + (ty * STRIDE) * PITCH + (tx * 16 + lpx) * STRIDE + 3;
+    for (int m = 0; m < MT; ++m)
 #pragma unroll
-      for (int tap = 0; tap < 9; ++tap) {
-        const int ky = tap / 3, kx = tap - ky * 3;
+      for (int tx = 0; tx < NTX; ++tx) acc[m][tx] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float* base = xs + g * PLANE + (ty * STRIDE) * PITCH + lpx * STRIDE + 3;
 #pragma unroll
-        for (int c4 = 0; c4 < 4; ++c4) {                             // k-step = tap * 4 + c4: channels 4 c4 + g
-          const float bv = base[c4 * 4 * PLANE + ky * PITCH + kx];
+    for (int tap = 0; tap < 9; ++tap) {
+      const int ky = tap / 3, kx = tap - ky * 3;
 #pragma unroll
-          for (int m = 0; m < MT; ++m)
-            acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[m][tap * 4 + c4], bv, acc[m], 0, 0, 0);
-        }
+      for (int c4 = 0; c4 < 4; ++c4) {                               // k-step = tap * 4 + c4: channels 4 c4 + g
+        float bv[NTX];
+#pragma unroll
+        for (int tx = 0; tx < NTX; ++tx) bv[tx] = base[c4 * 4 * PLANE + ky * PITCH + kx + tx * 16 * STRIDE];
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int tx = 0; tx < NTX; ++tx)
+            acc[m][tx] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[m][tap * 4 + c4], bv[tx], acc[m][tx], 0, 0, 0);
       }
-      const int oy = oy0 + ty, ox = ox0 + tx * 16 + lpx;
+    }
+    const int oy = oy0 + ty;
+#pragma unroll
+    for (int tx = 0; tx < NTX; ++tx) {
+      const int ox = ox0 + tx * 16 + lpx;
       if (oy < a.Ho && ox < a.Wo) {
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            float v = acc[m][q] + bias_r[m][q];
+            float v = acc[m][tx][q] + bias_r[m][q];
             if (a.relu) v = fmaxf(v, 0.f);
             ob[((long long)(16 * m + 4 * g + q) * a.Ho + oy) * a.Wo + ox] = v;
           }
@@ -196,21 +208,33 @@ __global__ __launch_bounds__(256) void conv3x3_c16_bf16_kernel(ConvArgs a) {
   const int iy0 = oy0 * STRIDE - 1;
   const int HW = a.H * a.W;
 
-  // weights -> registers: A[co = 16 m + lpx][k = 32 s + 8 g + j] = W[co][ci = 8 (g & 1) + j][tap = 2 s + (g >> 1)]
+  // weights -> registers: A[co = 16 m + lpx][k = 32 s + 8 g + j] = W[co][ci = 8 (g & 1) + j][tap = 2 s + (g >> 1)].
+  // Through LDS (round 4): the tensor is read ONCE per workgroup with coalesced loads and every lane picks its values
+  // with ds_reads, under the latency of the tile's loads -- straight from global memory each wave issued 40 MT dword
+  // gathers over 16 rows 576 bytes apart (32+ cache lines per instruction through the texture addresser the CU's 12
+  // waves share): level0 105 -> 91 us.
   cbf16x8 wh[MT][KS], wl[MT][KS];
+  auto weights_via_lds = [&]() {
+    constexpr int NWT = COUT * CIN * 9;
+    static_assert(NWT * 4 <= 4 * HALF, "the weights fit the tile buffer");
+    float* wsh = reinterpret_cast<float*>(xs);
+    for (int e = tid; e < NWT; e += 256) wsh[e] = a.w[e];
+    __syncthreads();
 #pragma unroll
-  for (int m = 0; m < MT; ++m)
+    for (int m = 0; m < MT; ++m)
 #pragma unroll
-    for (int s_ = 0; s_ < KS; ++s_) {
-      const int tap = 2 * s_ + (g >> 1);
+      for (int s_ = 0; s_ < KS; ++s_) {
+        const int tap = 2 * s_ + (g >> 1);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const float v = tap < 9 ? a.w[((16 * m + lpx) * CIN + 8 * (g & 1) + j) * 9 + tap] : 0.f;
-        const __bf16 h = (__bf16)v;
-        wh[m][s_][j] = h;
-        wl[m][s_][j] = (__bf16)(v - (float)h);
+        for (int j = 0; j < 8; ++j) {
+          const float v = tap < 9 ? wsh[((16 * m + lpx) * CIN + 8 * (g & 1) + j) * 9 + tap] : 0.f;
+          const __bf16 h = (__bf16)v;
+          wh[m][s_][j] = h;
+          wl[m][s_][j] = (__bf16)(v - (float)h);
+        }
       }
-    }
+    __syncthreads();                                                 // (the tile overwrites the buffer)
+  };
   // per-lane byte offset of the lane's tap in k-step s (tile cell of tap (ky, kx) relative to the output pixel's cell)
   int toff[KS];
 #pragma unroll
@@ -242,6 +266,7 @@ __global__ __launch_bounds__(256) void conv3x3_c16_bf16_kernel(ConvArgs a) {
         v[i][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, off, 0, 0));
       }
     }
+    weights_via_lds();                                               // (under the tile loads' latency)
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
       const int it = tid + 256 * i;
@@ -260,6 +285,7 @@ __global__ __launch_bounds__(256) void conv3x3_c16_bf16_kernel(ConvArgs a) {
       }
     }
   } else {
+    weights_via_lds();
 #pragma unroll 1
     for (int it = tid; it < NITEM; it += 256) {
       const int half = it / (IH * NC4), r = it - half * (IH * NC4);
@@ -297,30 +323,42 @@ __global__ __launch_bounds__(256) void conv3x3_c16_bf16_kernel(ConvArgs a) {
 #pragma unroll 1
   for (int rr = 0; rr < RPW; ++rr) {
     const int ty = wid * RPW + rr;
-#pragma unroll 1
-    for (int tx = 0; tx < TW / 16; ++tx) {
-      f32x4 acc[MT];
+    // the row's four 16-pixel tiles together: four independent accumulator chains per output-channel fragment (one
+    // tile at a time was ONE chain of 15 dependent MFMAs per wave -- the matrix pipe idled on its own latency)
+    constexpr int NTX = TW / 16;
+    f32x4 acc[MT][NTX];
 #pragma unroll
-      for (int m = 0; m < MT; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
-      const unsigned char* base = xs + ((ty * STRIDE) * IW + (tx * 16 + lpx) * STRIDE + 3) * 16;
+    for (int m = 0; m < MT; ++m)
 #pragma unroll
-      for (int s_ = 0; s_ < KS; ++s_) {
-        const cbf16x8 bh = *reinterpret_cast<const cbf16x8*>(base + toff[s_]);
-        const cbf16x8 bl = *reinterpret_cast<const cbf16x8*>(base + toff[s_] + 2 * HALF);
+      for (int tx = 0; tx < NTX; ++tx) acc[m][tx] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const unsigned char* base = xs + ((ty * STRIDE) * IW + lpx * STRIDE + 3) * 16;
 #pragma unroll
-        for (int m = 0; m < MT; ++m) {
-          acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[m][s_], bh, acc[m], 0, 0, 0);
-          acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[m][s_], bl, acc[m], 0, 0, 0);
-          acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[m][s_], bh, acc[m], 0, 0, 0);
-        }
+    for (int s_ = 0; s_ < KS; ++s_) {
+      cbf16x8 bh[NTX], bl[NTX];
+#pragma unroll
+      for (int tx = 0; tx < NTX; ++tx) {
+        bh[tx] = *reinterpret_cast<const cbf16x8*>(base + tx * 16 * STRIDE * 16 + toff[s_]);
+        bl[tx] = *reinterpret_cast<const cbf16x8*>(base + tx * 16 * STRIDE * 16 + toff[s_] + 2 * HALF);
       }
-      const int oy = oy0 + ty, ox = ox0 + tx * 16 + lpx;
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int tx = 0; tx < NTX; ++tx) {
+          acc[m][tx] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[m][s_], bh[tx], acc[m][tx], 0, 0, 0);
+          acc[m][tx] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[m][s_], bl[tx], acc[m][tx], 0, 0, 0);
+          acc[m][tx] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[m][s_], bh[tx], acc[m][tx], 0, 0, 0);
+        }
+    }
+    const int oy = oy0 + ty;
+#pragma unroll
+    for (int tx = 0; tx < NTX; ++tx) {
+      const int ox = ox0 + tx * 16 + lpx;
       if (oy < a.Ho && ox < a.Wo) {
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            float v = acc[m][q] + bias_r[m][q];
+            float v = acc[m][tx][q] + bias_r[m][q];
             if (a.relu) v = fmaxf(v, 0.f);
             ob[((long long)(16 * m + 4 * g + q) * a.Ho + oy) * a.Wo + ox] = v;
           }
