@@ -96,6 +96,8 @@ _SIGNATURES = {
     "cp_conv_mfma_prepare_batch": (c_int32, [_P, c_int32, c_int32, _P]),
     "cp_conv_mfma_forward": (c_int32, [_P, _P, c_int32, _P, _P, _P, _P] + [c_int32] * 6 + [_P]),
     "cp_conv_mfma_forward_strided": (c_int32, [_P, _P, c_int32, _P, _P, _P, _P] + [c_int32] * 7 + [_P]),
+    "cp_dla_base_pair_supported": (c_int32, [c_int32] * 2),
+    "cp_dla_base_pair_forward": (c_int32, [_P] * 6 + [c_int32] * 3 + [_P]),
     "cp_conv_mfma_forward_split": (c_int32, [_P, c_int32, _P, _P, _P, _P] + [c_int32] * 9 + [_P]),
     "cp_activation_split": (c_int32, [_P, _P] + [c_int32] * 4 + [_P]),
     "cp_activation_unsplit": (c_int32, [_P, _P] + [c_int32] * 4 + [_P]),

@@ -146,6 +146,34 @@ def conv_train(conv, x):
     return conv(x)
 
 
+def _base_pair(dla, x):
+    """level0 + level1 (folded) as one launch of cp_dla_base_pair_forward -- the 16-channel full-resolution map between
+    them stays in LDS; None when the layers / the map are not the kernel's (the caller runs them one by one)."""
+    c0, c1 = dla.level0[0], dla.level1[0]
+    if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and conv3x3.mfma_enabled()
+            and (c0.in_channels, c0.out_channels, c0.kernel_size, c0.stride, c0.padding, c0.dilation, c0.groups)
+            == (16, 16, (3, 3), (1, 1), (1, 1), (1, 1), 1)
+            and (c1.in_channels, c1.out_channels, c1.kernel_size, c1.stride, c1.padding, c1.dilation, c1.groups)
+            == (16, 32, (3, 3), (2, 2), (1, 1), (1, 1), 1)):
+        return None
+    B, _, H, W = x.shape
+    L = _C.lib()
+    if not L.cp_dla_base_pair_supported(H, W) or B > 65535:
+        return None
+    (w0, b0), (w1, b1) = dla._folded[1], dla._folded[2]
+    x = x.contiguous()
+    out = torch.empty((B, 32, (H - 1) // 2 + 1, (W - 1) // 2 + 1), dtype=torch.float32, device=x.device)
+    end = _C.kernel_timer.start(("conv_base_pair", 16, 32, H, W, B)) if _C.kernel_timer is not None else None
+    rc = L.cp_dla_base_pair_forward(_C.ptr(x), _C.ptr(w0.contiguous()), _C.ptr(b0), _C.ptr(w1.contiguous()), _C.ptr(b1),
+                                    _C.ptr(out), B, H, W, _C.stream())
+    if rc == -2:
+        return None
+    _C.check(rc, "cp_dla_base_pair_forward")
+    if end is not None:
+        end.record()
+    return out
+
+
 def _conv_folded(x, conv, wb, relu=False, residual=None):
     """conv with folded-BN weights, then ONE fused in-place pass: + bias (+ residual) (+ ReLU)."""
     if residual is None:
@@ -481,9 +509,14 @@ class DLA(nn.Module):
     def forward(self, x):
         pyramid = []
         if _use_folded(self):
-            for seq, wb in zip((self.base_layer, self.level0, self.level1), self._folded):
-                x = _conv_folded(x, seq[0], wb, relu=True)
-                if seq is not self.base_layer:
+            x = _conv_folded(x, self.base_layer[0], self._folded[0], relu=True)
+            y1 = _base_pair(self, x) if getattr(self, "skip_level0_output", False) else None
+            if y1 is not None:                      # level0 + level1 in one launch; nobody reads level0's map
+                pyramid += [None, y1]
+                x = y1
+            else:
+                for seq, wb in zip((self.level0, self.level1), self._folded[1:]):
+                    x = _conv_folded(x, seq[0], wb, relu=True)
                     pyramid.append(x)
             first_tree = 2
         elif self.training and x.is_cuda and all(len(q) == 3 for q in (self.base_layer, self.level0,
@@ -712,6 +745,7 @@ class DLASeg(nn.Module):
         self.first_level = int(np.log2(down_ratio))
         self.last_level = last_level
         self.base = globals()[base_name](pretrained=pretrained)
+        self.base.skip_level0_output = self.first_level >= 1     # dla_up reads the pyramid from first_level on
         channels = self.base.channels
         fl = self.first_level
         scales = [2 ** i for i in range(len(channels[fl:]))]

@@ -267,6 +267,15 @@ int cp_conv_mfma_forward(const float* const* xs, const int32_t* cs, int32_t nsrc
 int cp_conv_mfma_forward_strided(const float* const* xs, const int32_t* cs, int32_t nsrc, const void* wperm,
                                  const float* bias, const float* residual, float* out, int32_t B, int32_t H, int32_t W,
                                  int32_t Cout, int32_t taps, int32_t stride, int32_t relu, void* stream);
+/* level0 + level1 of the DLA base at inference as ONE launch (pose_dla_dcn.py:236-246,266-276, BatchNorm folded):
+ *   out = relu(conv3x3 stride 2 pad 1 (relu(conv3x3 pad 1 (x, w0) + b0), w1) + b1)
+ * x [B][16][H][W] -> out [B][32][(H-1)/2+1][(W-1)/2+1]; w0 [16][16][3][3], w1 [32][16][3][3], b0 / b1 may be null.
+ * The 16-channel full-resolution intermediate (the network's largest activation, one consumer) stays in LDS.
+ * split-bf16 x3 arithmetic in both layers.  W % 4 == 0 and a 16-byte aligned x (cp_dla_base_pair_supported), else
+ * CP_EUNSUPPORTED -- run the two layers through cp_conv_direct_forward_ex. */
+int cp_dla_base_pair_supported(int32_t H, int32_t W);
+int cp_dla_base_pair_forward(const float* x, const float* w0, const float* b0, const float* w1, const float* b1, float* out,
+                             int32_t B, int32_t H, int32_t W, void* stream);
 /* SPLIT activations (round 4; inference, between the two convolutions of a BasicBlock, pose_dla_dcn.py:38-66): a
  * float32 tensor [B][C][H][W] kept as two planes [hi | lo] of [B][C / 8][H][W][8 x bf16] (hi = bf16(v), lo =
  * bf16(v - hi): the halves the convolution's staging forms anyway; same bytes as float32; C % 8 == 0).  The producer's

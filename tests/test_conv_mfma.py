@@ -711,3 +711,47 @@ def test_residual_blocks_with_split_intermediate_equal_the_float32_route(case):
         assert _rel(z, full) <= 2 * TOL                        # two chained contractions
         if kind == "dla":
             assert torch.equal(blk(x, skip), ref)              # the module takes the same route
+
+
+# ---- level0 + level1 of the DLA base in one launch (csrc/conv_base_pair.hip) -------------------------------------------
+PAIR_SHAPES = [(1, 64, 128), (2, 37, 100), (1, 8, 4), (1, 5, 36), (2, 130, 72), (1, 1, 8)]
+
+
+@pytest.mark.parametrize("shape", PAIR_SHAPES, ids=["x".join(map(str, s)) for s in PAIR_SHAPES])
+def test_base_pair_kernel_matches_float64_and_the_separate_route(shape):
+    """cp_dla_base_pair_forward against relu(conv_s2(relu(conv(x)))) in float64 (2 chained split-bf16 contractions: 4e-5
+    of the max-norm) and against the two direct kernels it replaces; odd heights, maps smaller than a tile, borders."""
+    B, H, W = shape
+    L = _C.lib()
+    x = _t("pairx%s" % (shape,), (B, 16, H, W))
+    w0, b0 = _t("pairw0", (16, 16, 3, 3), 0.1), _t("pairb0", (16,), 0.2)
+    w1, b1 = _t("pairw1", (32, 16, 3, 3), 0.1), _t("pairb1", (32,), 0.2)
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    assert L.cp_dla_base_pair_supported(H, W)
+    out = torch.full((B, 32, Ho, Wo), float("nan"), device=DEV)
+    _C.check(L.cp_dla_base_pair_forward(P(x), P(w0), P(b0), P(w1), P(b1), P(out), B, H, W, _C.stream()), "pair")
+    assert torch.isfinite(out).all()
+    ref = F.relu(F.conv2d(F.relu(F.conv2d(x.double(), w0.double(), b0.double(), padding=1)), w1.double(), b1.double(),
+                          stride=2, padding=1))
+    assert _rel(out, ref) <= 2 * TOL
+    y0 = torch.empty((B, 16, H, W), device=DEV)
+    _C.check(L.cp_conv_direct_forward_ex(P(x), P(w0), P(b0), P(y0), B, 16, H, W, 16, 3, 1, 1, 1, 1, _C.stream()), "level0")
+    y1 = torch.empty((B, 32, Ho, Wo), device=DEV)
+    _C.check(L.cp_conv_direct_forward_ex(P(y0), P(w1), P(b1), P(y1), B, 16, H, W, 32, 3, 2, 1, 1, 1, _C.stream()), "level1")
+    assert _rel(out, y1.double()) <= 2 * TOL
+    out2 = torch.empty_like(out)
+    _C.check(L.cp_dla_base_pair_forward(P(x), P(w0), P(b0), P(w1), P(b1), P(out2), B, H, W, _C.stream()), "pair")
+    assert torch.equal(out, out2)                                   # run-to-run identical
+    # without biases
+    _C.check(L.cp_dla_base_pair_forward(P(x), P(w0), None, P(w1), None, P(out2), B, H, W, _C.stream()), "pair")
+    ref0 = F.relu(F.conv2d(F.relu(F.conv2d(x.double(), w0.double(), padding=1)), w1.double(), stride=2, padding=1))
+    assert _rel(out2, ref0) <= 2 * TOL
+
+
+def test_base_pair_kernel_refuses_widths_it_does_not_cover():
+    L = _C.lib()
+    assert not L.cp_dla_base_pair_supported(16, 30)
+    x = _t("pairrx", (1, 16, 16, 30))
+    w0, w1 = _t("pairw0", (16, 16, 3, 3), 0.1), _t("pairw1", (32, 16, 3, 3), 0.1)
+    out = torch.empty((1, 32, 8, 15), device=DEV)
+    assert L.cp_dla_base_pair_forward(P(x), P(w0), None, P(w1), None, P(out), 1, 16, 30, _C.stream()) == -2
