@@ -48,7 +48,8 @@
 extern "C" {
 #endif
 
-#define CP_ABI_VERSION 3   /* 3 (round 4): + cp_polydet_decode_ex, cp_dense_l1_*, cp_polydet_dense_targets; no signature changed */
+#define CP_ABI_VERSION 3   /* 3 (round 4): + cp_polydet_decode_ex, cp_dense_l1_*, cp_polydet_dense_targets, cp_conv_direct_forward_ex,
+                              cp_conv_mfma_forward_split, cp_activation_split / _unsplit, cp_dla_base_pair_*; no signature changed */
 
 enum {
   CP_OK = 0,
