@@ -147,7 +147,7 @@ struct CvArgs {
 // of the nine weight taps (ky, kx) feeds the class ((ky != 1), (kx != 1)) from the staged row / column offset
 // (ky == 0 ? 2 : 1, kx == 0 ? 2 : 1): grad_out is staged once and the matrix cores do exactly the convolution's flops.
 template <int MT, int RW, int TAPS, int KS = 1, int ST = 1, bool IG2 = false, bool PRE = false, bool OSPLIT = false>
-__global__ __launch_bounds__(256 * KS, KS > 1 ? 4 : 2) void conv_mfma_kernel(CvArgs a) {
+__global__ __launch_bounds__(256 * KS, KS > 1 ? (ST > 1 && TAPS == 9 ? 1 : 4) : 2) void conv_mfma_kernel(CvArgs a) {
   static_assert(!IG2 || (TAPS == 9 && KS == 1 && ST == 1), "IG2: 3x3, stride-1 staging, no split-K");
   static_assert(!PRE || (TAPS == 9 && ST == 1 && !IG2), "PRE: 3x3 / stride 1 forward");
   static_assert(!OSPLIT || !IG2, "split planes out: forward forms");
@@ -645,11 +645,16 @@ static int conv_dispatch(CvArgs& a, int B, int Cout, int taps, int stride, hipSt
     else launch(conv_mfma_kernel<2, 1, 1, 1, 2>, 2, 4, 1);
   } else if (stride == 2) {                          // 4-row tiles only (the staged tile is 9 x 65 pixels)
     const bool big = Cout > 32 && wgs(4, 4) >= 448;
+    // deep, small maps (256 -> 512 @64x128: 256 workgroups, one per CU, eight sequential chunks): two groups of waves take
+    // alternate chunks through their own staged tiles (2 x 75 KB of LDS: one workgroup per CU is all there is anyway)
+    const bool ks2 = !big && wgs(2, 4) <= 256 && a.nchunk >= 4;
     if (a.out_split) {
       if (big) launch(conv_mfma_kernel<4, 1, 9, 1, 2, false, false, true>, 4, 4, 1);
+      else if (ks2) launch(conv_mfma_kernel<2, 1, 9, 2, 2, false, false, true>, 2, 4, 2);
       else launch(conv_mfma_kernel<2, 1, 9, 1, 2, false, false, true>, 2, 4, 1);
     } else {
       if (big) launch(conv_mfma_kernel<4, 1, 9, 1, 2>, 4, 4, 1);
+      else if (ks2) launch(conv_mfma_kernel<2, 1, 9, 2, 2>, 2, 4, 2);
       else launch(conv_mfma_kernel<2, 1, 9, 1, 2>, 2, 4, 1);
     }
   } else if (taps == 9) {                            // split-plane input / output: the same tile choice, other staging / epilogue
