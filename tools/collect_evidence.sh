@@ -67,6 +67,9 @@ fi
 if want probes; then
   run probe_decode "$P/${tag}_decode_probe.txt" -- bash -c "timeout -k 10 300 python3 tools/probe_decode.py > $P/${tag}_decode_probe.txt"
   run probe_bwd "$P/${tag}_dcn_bwd_probe.txt" -- bash -c "timeout -k 10 300 python3 tools/probe_dcn_bwd.py > $P/${tag}_dcn_bwd_probe.txt"
+  run probe_conv_split "$P/${tag}_conv_split_probe.txt" -- bash -c "timeout -k 10 200 python3 tools/probe_conv_split.py > $P/${tag}_conv_split_probe.txt"
+  run probe_base_pair "$P/${tag}_base_pair_probe.txt" -- bash -c "timeout -k 10 200 python3 tools/probe_base_pair.py > $P/${tag}_base_pair_probe.txt"
+  run probe_conv_direct "$P/${tag}_conv_direct_bf16_probe.txt" -- bash -c "timeout -k 10 200 python3 tools/probe_conv_direct_bf16.py > $P/${tag}_conv_direct_bf16_probe.txt"
 fi
 say "done (failed=$failed)"
 exit $failed
