@@ -61,6 +61,13 @@ def test_argument_validation_without_gpu():
     # no K split at this shape: only the permuted weights of the split-bf16 contraction
     # (8 sixteen-row tiles x 8 chunks of 8 channels x 3 k-steps x hi/lo x 64 lanes x 16 B)
     assert L.cp_dcn_v2_forward_workspace_bytes(_C.DcnShape(1, 64, 256, 512, 64, 3, 3, 1, 1, 1, 1)) == 8 * 8 * 3 * 2 * 64 * 16
+    # round 4: split activations and the base pair validate on the host too
+    assert L.cp_dla_base_pair_supported(1024, 2048) == 1 and L.cp_dla_base_pair_supported(37, 100) == 1
+    assert L.cp_dla_base_pair_supported(64, 30) == 0 and L.cp_dla_base_pair_supported(0, 64) == 0
+    assert L.cp_dla_base_pair_supported(16384, 16384) == 0                       # (32-bit offsets within an image)
+    assert L.cp_dla_base_pair_forward(None, None, None, None, None, None, 1, 64, 64, None) == -1
+    assert L.cp_activation_split(None, None, 1, 16, 8, 8, None) == -1
+    assert L.cp_conv_mfma_forward_split(None, 1, None, None, None, None, 0, 1, 64, 8, 32, 64, 9, 1, 0, None) == -1
 
 
 def test_ops_refuse_host_tensors():
