@@ -22,6 +22,11 @@
 //     fragment reads for 6 MT RW MFMAs: the two operand streams load the two pipes (L1 and LDS) about equally.
 //   * 256 threads; LDS = (4 RW + 2) * 34 * 128 B (43.5 KB for RW = 2: three workgroups per CU; while one stages, the
 //     others keep the matrix cores busy).
+//   * float32 output: the instruction is issued as mfma(B, A) -- the operands share one register layout -- so the tile
+//     comes out transposed (lane = 4 consecutive pixels of one channel): one 16-byte store / residual / mask access per
+//     tile.  Split-plane output (template OSPLIT) and the stride-2 gradient (IG2) keep D[co][px] (lane = 4 channels).
+//   * split planes (round 4): [hi | lo] x [C / 8][H][W][8 x bf16] written by a producer's epilogue, staged by the consumer
+//     (template PRE) with 16-byte loads and no conversion arithmetic: cp_conv_mfma_forward_split.
 #include "cp_common.h"
 
 #include <type_traits>
