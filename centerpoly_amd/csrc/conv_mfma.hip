@@ -1134,7 +1134,10 @@ int cp_conv_mfma_wgrad(const float* x, const float* go, float* gw, int32_t B, in
   const int MTW = Cout <= 32 ? 1 : 2;
   const int n_co = (Cout + 32 * MTW - 1) / (32 * MTW);
   const int pairs = a.n_ci * n_co;
-  int nsplit = (512 + pairs - 1) / pairs;                            // ~2 workgroups per CU
+  // ~1 workgroup (8 waves) per CU: every workgroup adds its whole partial gradient to gw with float atomics at the end, so
+  // the atomics scale with the workgroup count -- 512 workgroups (two per CU) ran the same contraction 14-18 % SLOWER
+  // (4 x 128 -> 128 @128x256: 179 vs 150 us; tools/probe history in DESIGN 4.13), the second workgroup bought nothing
+  int nsplit = (256 + pairs - 1) / pairs;
   if (nsplit > a.ntiles) nsplit = a.ntiles;
   a.tiles_per_wg = (a.ntiles + nsplit - 1) / nsplit;
   nsplit = (a.ntiles + a.tiles_per_wg - 1) / a.tiles_per_wg;
