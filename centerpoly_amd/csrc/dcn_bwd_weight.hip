@@ -644,10 +644,11 @@ int cp_dcn_bwd_weight2(const cp_dcn_shape* s, const float* x, const float* offse
   const int slab = 64;      // 128-wide slabs halve the sampling per MFMA but leave one workgroup per CU: measured
                             // slower (0.72 vs 0.65 ms at 128->128 @128x256 x4)
   const int slabs = (s->Cout + slab - 1) / slab;
-  // tiles per run: about two rounds of workgroups on 256 CUs x 2 (every extra tile amortises the flush, whose
-  // float atomics all land in the same Cout x Cin x 9 block)
+  // tiles per run: ONE round of workgroups on 256 CUs x 2 (every extra tile amortises the flush, whose float atomics all
+  // land in the same Cout x Cin x 9 block; round 4 sweep at the six layer shapes: 1024 / 768 / 512 / 256 workgroups =
+  // 0.453 / 0.542 / 0.449 / 0.533 ms at 64 -> 64 @256x512 x4, 0.428 / 0.448 / 0.417 / 0.499 at 128 -> 128 @128x256 x4)
   const long long units = (long long)a.ntiles * s->B * chunks * slabs;
-  int T = (int)((units + 1023) / 1024);
+  int T = (int)((units + 511) / 512);
   if (T < 1) T = 1;
   if (T > a.ntiles) T = a.ntiles;
   a.T = T;
