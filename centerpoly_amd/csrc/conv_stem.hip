@@ -61,8 +61,16 @@ struct StemArgs {
 template <int S, int MT>
 __global__ __launch_bounds__(256, 2) void conv_stem_kernel(StemArgs a) {
   constexpr int IR = S * (TH - 1) + 7;             // staged input rows: S y0 - 3 .. S (y0 + TH - 1) + 3
-  constexpr int PLANE = 3 * IR * TW;               // records per half
+  // LDS addressing of record xr of a (channel, row): RP = 34 slots per row, one pad slot after every 16 records.  The
+  // staging writes record r of segment seg of four rows per 16-lane group: with 32 slots per row and the segments 8
+  // apart every lane of a group fell on banks {0, 32} + 4 r -- 8-way conflicts, 67 % of the LDS-active cycles (round-4
+  // PMC passes, 74.9 us); with the pad the segments start at dwords {0, 32, 68, 100} and the rows 136 apart: the 16
+  // lanes take the 16 different 4-bank groups, and a fragment read (the 16 records of one 16-aligned tile) stays
+  // contiguous.
+  constexpr int RP = TW + TW / 16;                 // 34 slots per row
+  constexpr int PLANE = 3 * IR * RP;               // slots per half
   __shared__ bf16x8 Xs[2 * PLANE];
+  auto slot = [](int xr) { return xr + (xr >> 4); };
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, g = lane >> 4, c = lane & 15;
   const int cot = blockIdx.x % a.ncot, tile = blockIdx.x / a.ncot;
   const int x0 = (tile % a.tiles_x) * TW, y0 = (tile / a.tiles_x) * TH, b = blockIdx.y;
@@ -109,7 +117,7 @@ __global__ __launch_bounds__(256, 2) void conv_stem_kernel(StemArgs a) {
         }
         typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
         u32x4* Xu = reinterpret_cast<u32x4*>(Xs);
-        const int u0 = (ci * IR + row) * TW + 8 * seg;
+        const int u0 = (ci * IR + row) * RP + 8 * seg + (seg >> 1);
 #pragma unroll
         for (int r = 0; r < 8; ++r) {                          // record r starts at column offset S r (pair S r / 2)
           u32x4 rh, rl;
@@ -130,8 +138,9 @@ __global__ __launch_bounds__(256, 2) void conv_stem_kernel(StemArgs a) {
         }
       }
     } else {
-      for (int u = tid; u < PLANE; u += 256) {
+      for (int u = tid; u < 3 * IR * TW; u += 256) {
         const int xr = u % TW, row = (u / TW) % IR, ci = u / (TW * IR);
+        const int su = (ci * IR + row) * RP + slot(xr);
         const int gy = S * y0 - 3 + row, gx0 = S * (x0 + xr) - 4;
         const bool rok = gy >= 0 && gy < a.H;
         float v[8];
@@ -148,8 +157,8 @@ __global__ __launch_bounds__(256, 2) void conv_stem_kernel(StemArgs a) {
           h[j] = hh;
           l[j] = (__bf16)(v[j] - (float)hh);
         }
-        Xs[u] = h;
-        Xs[PLANE + u] = l;
+        Xs[su] = h;
+        Xs[PLANE + su] = l;
       }
     }
   }
@@ -178,7 +187,7 @@ __global__ __launch_bounds__(256, 2) void conv_stem_kernel(StemArgs a) {
 #pragma unroll
     for (int n = 0; n < 4; ++n) {
       const int yy = wid * 2 + (n >> 1);                       // output row within the tile
-      const int idx = (ci * IR + S * yy + ky) * TW + (n & 1) * 16 + c;
+      const int idx = (ci * IR + S * yy + ky) * RP + slot((n & 1) * 16 + c);
       bh[n] = Xs[idx];
       bl[n] = Xs[PLANE + idx];
     }
