@@ -4,11 +4,16 @@
 set -u
 cd "$(dirname "$0")/.."
 tag=${1:-r04}
-out=gpurun_out/pmc_step_lds_$tag
+out=gpurun_out/pmc_step_lds_${PMC_LEG:-infer}_$tag
 mkdir -p $out
 export TMPDIR=/tmp
-B="python3 bench.py --config 2 --steps 3 --warmup 2 --no_cpu_baseline --no_train_point --no_detector_point --no_offset_points --no_other_configs --no_exact_point"
-timeout -k 10 400 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_WAIT_INST_ANY --output-format csv -d $out/p1 -o p1 -- $B > $out/p1.log 2>&1
+# PMC_LEG=train: the B = 4 training leg instead (the inference leg shrunk to one step)
+if [ "${PMC_LEG:-infer}" = train ]; then
+  B="python3 bench.py --config 2 --steps 1 --warmup 1 --no_cpu_baseline --no_detector_point --no_offset_points --no_other_configs --no_exact_point"
+else
+  B="python3 bench.py --config 2 --steps 3 --warmup 2 --no_cpu_baseline --no_train_point --no_detector_point --no_offset_points --no_other_configs --no_exact_point"
+fi
+timeout -k 10 500 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_WAIT_INST_ANY --output-format csv -d $out/p1 -o p1 -- $B > $out/p1.log 2>&1
 rc=$?; echo "pass rc=$rc"
 python3 - "$out" <<'P'
 import csv, glob, sys, collections
